@@ -1,0 +1,233 @@
+/*
+ * jsg.h -- C-ABI of the MI355X-native (gfx950) STFT spectrogram engine.
+ *
+ * This is the drop-in boundary for the hot path of JoergBitzer/JadeSpectrogram
+ * (sliding-window FFT -> |X|^2 -> channel mix -> 10*log10 -> colour-map LUT -> ARGB).
+ * Host code (C++/JUCE: jadespectrogram_amd/host/Spectrogram.h, or any FFI) calls HIP
+ * only through these entry points: plain pointers and sizes, no C++/torch types.
+ *
+ * Every entry point cites the reference interface it replaces (paths are relative to the
+ * reference tree, i.e. JadeSpectrogram/<file>:<line>).
+ *
+ * Conventions
+ *   - return value: JSG_OK (0) or a negative jsg_status, except where the reference returns a
+ *     count (jsg_get_mem: number of new columns, -1 on size mismatch, like Spectrogram.cpp:297-298).
+ *   - nothing throws across this boundary; jsg_last_error() gives the text of the last failure.
+ *   - an engine is bound to the HIP device that is current when it is created; one engine per GPU,
+ *     one process per GPU for multi-GPU use (channels/streams are sharded, no collective needed).
+ *   - threading: one producer thread (process_*) and one consumer thread (get_mem / display_*),
+ *     serialised internally by a mutex (the reference's m_protect, made to cover the readers too).
+ *   - there is NO CPU fallback: every compute entry point fails with JSG_ERR_HIP / JSG_ERR_NO_DEVICE
+ *     when no gfx950 device is usable.
+ */
+#ifndef JSG_H_
+#define JSG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JSG_ABI_VERSION 1
+
+typedef enum jsg_status {
+    JSG_OK = 0,
+    JSG_ERR_SIZE_MISMATCH = -1, /* the reference's "-1" (Spectrogram.cpp:297-298) */
+    JSG_ERR_INVALID = -2,       /* bad argument */
+    JSG_ERR_UNSUPPORTED = -3,   /* e.g. FFT size outside 512..8192 or not a power of two */
+    JSG_ERR_HIP = -4,           /* a HIP call failed; see jsg_last_error */
+    JSG_ERR_NO_DEVICE = -5,
+    JSG_ERR_NOMEM = -6
+} jsg_status;
+
+/* Spectrogram::ChannelMixMode, Spectrogram.h:84-91 (same order). PER_CHANNEL is an extension:
+ * no mix, one spectrogram per channel (what channel-sharded multi-GPU runs produce). */
+typedef enum jsg_mix_mode {
+    JSG_MIX_ABSMEAN = 0, JSG_MIX_MAX = 1, JSG_MIX_MIN = 2, JSG_MIX_LEFT = 3, JSG_MIX_RIGHT = 4,
+    JSG_MIX_PER_CHANNEL = 100,
+    JSG_MIX_SUM = 101           /* extension: plain sum over the local channels, no divide (partial of a
+                                   cross-GPU AbsMean; finished by jsg_db_from_power_launch after the reduce) */
+} jsg_mix_mode;
+
+/* Spectrogram::Windows, Spectrogram.h:92-100 (same order; the GUI casts combo indices to it,
+ * Spectrogram.cpp:409). */
+typedef enum jsg_window {
+    JSG_WIN_RECT = 0, JSG_WIN_HANN = 1, JSG_WIN_HAMMING = 2, JSG_WIN_BLACKMANHARRIS = 3,
+    JSG_WIN_FLATTOP = 4, JSG_WIN_HANNPOISSON = 5
+} jsg_window;
+
+/* Spectrogram::FeedPercentage, Spectrogram.h:101-107. */
+typedef enum jsg_feed { JSG_FEED_100 = 0, JSG_FEED_50 = 1, JSG_FEED_25 = 2, JSG_FEED_10 = 3 } jsg_feed;
+
+/* CColorPalette scheme ids, CColorpalette.h:9-18. */
+typedef enum jsg_colorscheme {
+    JSG_CM_MONO = 0, JSG_CM_BW = 1, JSG_CM_HOT = 2, JSG_CM_RAINBOW = 3, JSG_CM_VIRIDIS = 4,
+    JSG_CM_PLASMA = 5, JSG_CM_JADE = 6
+} jsg_colorscheme;
+
+int jsg_abi_version(void);
+/* Number of usable gfx950 devices (0 when there is none; never initialises a context). */
+int jsg_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * 1. Host-side precompute that feeds the kernels (pure integer / double arithmetic, no GPU).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* m_feed_samples = int(m_feed_percent*0.01*m_fftsize+0.5)           -- Spectrogram.cpp:216 */
+int jsg_feed_samples(float feed_percent, int fftsize);
+/* m_memsize_blocks = int(m_memsize_s*m_fs/m_feed_samples + 0.5)     -- Spectrogram.cpp:217 */
+int jsg_memsize_blocks(float memsize_s, float fs, int feed_samples);
+/* Spectrogram::getnextpowerof2                                       -- Spectrogram.cpp:171-176 */
+int jsg_next_power_of_2(float fftsize_ms, float fs);
+/* Spectrogram::setWindowFkt: n RMS-normalised window samples        -- Spectrogram.cpp:239-293 */
+int jsg_window_build(int window, int n, float* out);
+/* CColorPalette::ComputeColors: n_colors ints 0x00RRGGBB             -- CColorpalette.cpp:106-339 */
+int jsg_colormap_build(int n_colors, int scheme, int32_t* lut_out);
+/* CColorPalette::setValueRange: resolves (lo,hi) -> m_Min, m_Max, m_AccessMult -- CColorpalette.cpp:39-54 */
+int jsg_colormap_range(int n_colors, float lo, float hi, float* vmin, float* vmax, float* access_mult);
+
+/* ------------------------------------------------------------------------------------------------
+ * 2. Stateless device operations.  Every data pointer is a DEVICE pointer on the current device;
+ *    `stream` is a hipStream_t (NULL = default stream).  Asynchronous: they only enqueue.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* FFT plan: twiddle / window tables resident in HBM for one (fft size, window).  Replaces the
+ * `spectrum m_fft` member + m_window (Spectrogram.h:157-159; Spectrogram.cpp:215, :239-293).
+ * `window` = n host floats; it is multiplied by sqrt(power_scale) when the tables are built. */
+typedef struct jsg_plan jsg_plan;
+int jsg_plan_create(jsg_plan** out, int n, const float* window, float power_scale);
+int jsg_plan_destroy(jsg_plan* plan);
+int jsg_plan_fft_size(const jsg_plan* plan);
+
+/* One launch of the fused kernel: framing + window + real FFT + |X|^2 + channel mix + 10*log10
+ * + ring store.  Replaces the body of Spectrogram::processSynchronBlock's frame loop
+ * (Spectrogram.cpp:50-119) incl. computePowerSpectrum (:137-145) and spectrum::power (:144).
+ *
+ * Frame j (j = first_frame .. first_frame+n_frames-1) of channel c reads n samples starting at
+ *     in[c*in_pitch + (j / feedblocks)*n + (j % feedblocks)*hop]
+ * (for a regular hop this is j*hop; the split reproduces the reference's irregular `perc10` hop).
+ * The caller provides the stream WITH the reference's n leading zeros if it wants the reference's
+ * time line; the engine API below does that itself.
+ * Column i of this launch is written to ring column (ring_pos + i) % ring_width:
+ *     out_db[col*out_pitch + bin],  bin = 0..n/2          (per-channel mode: + c*out_channel_pitch)
+ */
+typedef struct jsg_stft_args {
+    const float* in;
+    int64_t in_pitch;        /* floats between channel rows */
+    int32_t channels;
+    int32_t hop;
+    int32_t feedblocks;
+    int32_t mix_mode;        /* jsg_mix_mode */
+    int64_t first_frame;
+    int64_t n_frames;
+    float* out_db;
+    int64_t out_pitch;       /* floats between ring columns (>= n/2+1) */
+    int64_t out_channel_pitch;
+    int32_t ring_width;
+    int32_t ring_pos;
+    int32_t linear_out;      /* 0: dB = 10*log10(p + 1e-11f) (the reference's column); 1: mixed linear power p */
+    int32_t reserved;
+} jsg_stft_args;
+int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* args, void* stream);
+
+/* out[i] = 10*log10(power[i]/divisor + 1e-11f), i < count: the tail of the mix (reference Spectrogram.cpp:74,107)
+ * for partial sums that were reduced across GPUs (JSG_MIX_SUM).  In place (out == power) is allowed. */
+int jsg_db_from_power_launch(const float* power, float* out, int64_t count, float divisor, void* stream);
+
+/* Colour loop: dB ring columns -> ARGB pixels (and/or 8-bit palette indices).
+ * Replaces the pixel loops of SpectrogramComponent::timerCallback (Spectrogram.cpp:632-648,
+ * :673-680, :693-700) with CColorPalette::getRGBColor inlined (CColorpalette.h:32-47):
+ *     pixel(x, height-1-bin) = lut[index(db[col][bin])] | 0xFF000000
+ * for i in [0,n_cols): col = (col_first+i) % ring_width, x = (x_first+i) % x_wrap.
+ * Image layout is row-major [height][img_pitch] (what juce::Image::BitmapData exposes). */
+typedef struct jsg_colormap_args {
+    const float* db;
+    int64_t db_pitch;
+    int32_t ring_width;
+    int32_t height;          /* bins = n/2+1 */
+    int32_t col_first;
+    int32_t n_cols;
+    int32_t x_first;
+    int32_t x_wrap;          /* image width */
+    const int32_t* lut;      /* device, n_colors entries 0x00RRGGBB */
+    int32_t n_colors;
+    float vmin, vmax, access_mult;   /* from jsg_colormap_range */
+    uint32_t* argb_out;      /* may be NULL */
+    int64_t argb_pitch;      /* pixels between image rows */
+    uint8_t* index_out;      /* may be NULL; requires n_colors <= 256 */
+    int64_t index_pitch;
+} jsg_colormap_args;
+int jsg_colormap_launch(const jsg_colormap_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 3. Engine: the state of class Spectrogram (Spectrogram.h:81-169) living on the GPU.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct jsg_engine jsg_engine;
+
+/* Spectrogram::Spectrogram() defaults (Spectrogram.cpp:16-24): fs 48000, n 1024, feed 100 %, 1 s memory,
+ * Hann, AbsMean.  `channels` is explicit (the plugin never calls setchannels). */
+int jsg_create(jsg_engine** out, int channels);
+int jsg_destroy(jsg_engine* e);
+const char* jsg_last_error(const jsg_engine* e);   /* e may be NULL: last error of the calling thread */
+
+/* setters: each rebuilds the memory like Spectrogram::buildmem (Spectrogram.cpp:213-238) */
+int jsg_set_samplerate(jsg_engine* e, float fs);                 /* Spectrogram.cpp:148-152 */
+int jsg_set_channels(jsg_engine* e, int channels);               /* :153-157 */
+int jsg_set_fft_size(jsg_engine* e, int n);                      /* :160-170 */
+int jsg_set_closest_fft_size_ms(jsg_engine* e, float ms);        /* :177-183 */
+int jsg_set_memory_time_s(jsg_engine* e, float seconds);         /* :184-188 */
+int jsg_set_feed_percent(jsg_engine* e, int feed);               /* :189-211, jsg_feed */
+int jsg_set_feed_percent_ext(jsg_engine* e, float percent);      /* extension: any overlap, e.g. 12.5 */
+int jsg_set_pause_mode(jsg_engine* e, int paused);               /* Spectrogram.h:122 */
+int jsg_set_window(jsg_engine* e, int window);                   /* Spectrogram.h:123 */
+int jsg_set_window_table(jsg_engine* e, const float* w, int n);  /* extension: caller-supplied window */
+int jsg_set_mix_mode(jsg_engine* e, int mode);                   /* m_mode has no setter in the reference (:21) */
+int jsg_set_power_scale(jsg_engine* e, float scale);             /* normalisation of spectrum::power, default 1 */
+
+int jsg_get_spectrum_size(const jsg_engine* e);                  /* Spectrogram.h:127 */
+int jsg_get_memory_size(const jsg_engine* e);                    /* Spectrogram.h:128 */
+float jsg_get_samplerate(const jsg_engine* e);                   /* Spectrogram.h:130 */
+int jsg_get_fft_size(const jsg_engine* e);
+int jsg_get_feed_samples(const jsg_engine* e);
+int jsg_get_feedblocks(const jsg_engine* e);
+int jsg_get_channels(const jsg_engine* e);
+int jsg_get_window(const jsg_engine* e, float* out, int n);      /* copy of m_window */
+
+/* Spectrogram::processSynchronBlock (Spectrogram.cpp:37-135): `planar` = channels host pointers to
+ * fft-size samples each.  Enqueues H2D copy + one kernel launch; returns without waiting. */
+int jsg_process_block(jsg_engine* e, const float* const* planar);
+/* The same for n_blocks consecutive blocks in one launch: samples[c*pitch + i], i < n_blocks*n. */
+int jsg_process_blocks(jsg_engine* e, const float* samples, int64_t pitch, int n_blocks);
+/* The same with the samples already in HBM (device pointer, same layout); no host copy. */
+int jsg_process_blocks_device(jsg_engine* e, const float* d_samples, int64_t pitch, int n_blocks);
+
+/* Spectrogram::getMem (Spectrogram.cpp:295-331): dst is the caller's dense [dst_columns][n/2+1]
+ * buffer; copies all columns when at least a ring-full is new, else only the new ones (in place,
+ * wrap-aware); returns the new-column count and zeroes it, -1 on size mismatch. */
+int jsg_get_mem(jsg_engine* e, float* dst, int dst_columns, int* pos);
+/* Device pointer / geometry of the dB ring (stays valid until the next setter). */
+int jsg_ring_device(jsg_engine* e, float** d_ring, int64_t* pitch, int* width, int* pos);
+int jsg_sync(jsg_engine* e);
+void* jsg_stream(jsg_engine* e);                                  /* the engine's hipStream_t */
+
+/* ------------------------------------------------------------------------------------------------
+ * 4. Display: the colour half of SpectrogramComponent::timerCallback (Spectrogram.cpp:590-731).
+ * ------------------------------------------------------------------------------------------------ */
+/* CColorPalette(n_colors, scheme) / setColorSceme (Spectrogram.cpp:337, :400); forces a full recolour */
+int jsg_display_set_colormap(jsg_engine* e, int n_colors, int scheme);
+/* m_isRunningDisplay (Spectrogram.cpp:745-759) */
+int jsg_display_set_running(jsg_engine* e, int running);
+/* m_recomputeAll = true (colour sliders, Spectrogram.cpp:370,379) */
+int jsg_display_invalidate(jsg_engine* e);
+/* One timer tick: consumes the new columns (like getMem), colours them (all of them when a recolour is
+ * pending) and writes the [height][width] ARGB image into host memory `argb` (`pitch` pixels per row).
+ * min_color/max_color are the slider values (Spectrogram.cpp:614-617). */
+int jsg_display_update(jsg_engine* e, float min_color, float max_color, uint32_t* argb, int64_t pitch,
+                       int* new_vals, int* pos);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JSG_H_ */

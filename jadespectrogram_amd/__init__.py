@@ -1,0 +1,12 @@
+"""jadespectrogram_amd -- MI355X-native (gfx950) STFT spectrogram engine behind the reference's Spectrogram API.
+
+The compute path is hand-written HIP in libjsg.so (csrc/), reached through the C-ABI of include/jsg.h.
+Importing this package does not load the library; the first call does, and fails loudly if it is missing.
+"""
+from . import capi  # noqa: F401
+from .capi import JsgError  # noqa: F401
+from .spectrogram import (CColorPalette, Plan, Spectrogram, SpectrogramDisplay, colormap, colormap_lut,  # noqa: F401
+                          colormap_range, feed_samples, memsize_blocks, next_power_of_2, stft_db, window)
+
+__all__ = ["Spectrogram", "SpectrogramDisplay", "CColorPalette", "Plan", "stft_db", "colormap", "window", "colormap_lut",
+           "colormap_range", "feed_samples", "memsize_blocks", "next_power_of_2", "JsgError", "capi"]

@@ -1,0 +1,63 @@
+"""In-tree build of libjsg.so (hand-written HIP for gfx950 + the C-ABI).  hipcc cross-compiles without a GPU."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libjsg.so")
+
+SOURCES = ["jsg_kernels.hip", "jsg_engine.cpp", "jsg_host_math.cpp"]
+HEADERS = ["jsg_internal.h", "jsg_colormap_tables.inc", os.path.join(ROOT, "include", "jsg.h")]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libjsg.so cannot be built (there is no CPU fallback)")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/* into jadespectrogram_amd/libjsg.so (only what is out of date)."""
+    hipcc = _hipcc()
+    objdir = os.path.join(PKG, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            cmd = [hipcc, "-std=c++17", "-O3", "-fPIC", "-c", s, "-o", o, "-I", os.path.join(ROOT, "include")]
+            if src.endswith(".hip"):
+                cmd += [f"--offload-arch={ARCH}"]
+            else:
+                # host translation units: keep float arithmetic exactly as written (bit parity with the reference)
+                cmd += ["-ffp-contract=off", "-D__HIP_PLATFORM_AMD__"]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,678 @@
+// Hand-written HIP kernels for gfx950 (MI355X, CDNA4): the STFT -> dB hot path and the colour loop.
+//
+//   stft_db_kernel   one wavefront (64 lanes; two frames per wave at N=512) transforms one real frame:
+//                    coalesced 8-byte loads of the frame straight from the audio stream in HBM (the 50 %..87.5 %
+//                    overlap between neighbouring frames is served by L1/L2: neighbouring frames are mapped to the
+//                    same workgroup and, through the XCD-aware block remap, to the same XCD), window multiply,
+//                    N/2-point complex FFT as three register-resident radix stages (P = N/128 complex values per
+//                    lane) with two wave-private, bank-conflict-free LDS exchanges (no workgroup barrier anywhere),
+//                    real-split post pass, |X|^2, channel mix, 10*log10 on the hardware log unit, 256-byte
+//                    coalesced ring stores.  No MFMA: the path is bandwidth / VALU-issue bound, not a contraction.
+//                    Replaces Spectrogram.cpp:50-119 + :137-145 + spectrum::power (call site :144) of the reference.
+//   colormap_kernel  dB ring columns -> ARGB image rows (transpose through LDS so both sides are coalesced),
+//                    CColorPalette::getRGBColor inlined.  Replaces Spectrogram.cpp:632-648 / :673-680 / :693-700.
+//
+// The index algebra, the twiddle tables and the LDS layouts are modelled and checked in tools/fft_model.py.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <new>
+#include <utility>
+#include <vector>
+
+#include "../../include/jsg.h"
+#include "jsg_internal.h"
+
+namespace jsg {
+
+// ------------------------------------------------------------------------------------------------------------
+// small complex helpers (float2 = re, im)
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 w) {
+    return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+}
+
+// cos/sin(2*pi*i/32), i = 0..15 (compile-time twiddles of the in-register radix butterflies)
+__device__ constexpr float kCos32[16] = {
+    1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+    0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f,
+    0.0f, -0.19509032201612826785f, -0.38268343236508977173f, -0.55557023301960222474f,
+    -0.70710678118654752440f, -0.83146961230254523708f, -0.92387953251128675613f, -0.98078528040323044913f};
+__device__ constexpr float kSin32[16] = {
+    0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
+    0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f,
+    1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+    0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
+
+// v * exp(-2*pi*i*J/R), J < R/2, R in {2,4,8,16,32}; trivial factors cost no multiply
+template <int J, int R>
+__device__ __forceinline__ float2 mul_w(float2 v) {
+    constexpr int idx = J * (32 / R);
+    if constexpr (idx == 0) {
+        return v;
+    } else if constexpr (idx == 8) {
+        return make_float2(v.y, -v.x);
+    } else if constexpr (idx == 4) {
+        constexpr float c = 0.70710678118654752440f;
+        return make_float2((v.x + v.y) * c, (v.y - v.x) * c);
+    } else if constexpr (idx == 12) {
+        constexpr float c = 0.70710678118654752440f;
+        return make_float2((v.y - v.x) * c, -(v.x + v.y) * c);
+    } else {
+        constexpr float wr = kCos32[idx], wi = -kSin32[idx];
+        return make_float2(v.x * wr - v.y * wi, v.x * wi + v.y * wr);
+    }
+}
+
+// In-register decimation-in-frequency DFT of R points, natural order in and out (the bit reversal is a
+// compile-time renaming of registers).  R = 8: 56 VALU ops, R = 16: 168.
+template <int R>
+__device__ __forceinline__ void dft(float2 (&x)[R]);
+
+template <int R, int J>
+struct DifLayer {
+    static __device__ __forceinline__ void run(const float2 (&x)[R], float2 (&a)[R / 2], float2 (&b)[R / 2]) {
+        a[J] = cadd(x[J], x[J + R / 2]);
+        b[J] = mul_w<J, R>(csub(x[J], x[J + R / 2]));
+        if constexpr (J + 1 < R / 2) DifLayer<R, J + 1>::run(x, a, b);
+    }
+};
+
+template <int R>
+__device__ __forceinline__ void dft(float2 (&x)[R]) {
+    if constexpr (R == 2) {
+        const float2 a = x[0], b = x[1];
+        x[0] = cadd(a, b);
+        x[1] = csub(a, b);
+    } else if constexpr (R > 2) {
+        float2 a[R / 2], b[R / 2];
+        DifLayer<R, 0>::run(x, a, b);
+        dft<R / 2>(a);
+        dft<R / 2>(b);
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q) {
+            x[2 * q] = a[q];
+            x[2 * q + 1] = b[q];
+        }
+    }
+}
+
+// Lanes of one wavefront run in lock-step, so a wave-private LDS exchange needs no s_barrier; what it does need is
+// that the COMPILER keeps the stores ahead of the loads that other lanes of the same wave perform.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// two floats that are only 4-byte aligned (odd hop sizes such as the reference's perc10 hop of 205 samples)
+struct __attribute__((packed, aligned(4))) f2u {
+    float x, y;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// per-size configuration (mirrors tools/fft_model.py CONFIGS; layouts found by its conflict search)
+// ------------------------------------------------------------------------------------------------------------
+template <int N_, int R1_, int R2_, int R3_, int L_, int S1_, int AX_, int AY_, int AZ_, int WPB_, bool REGT_>
+struct Cfg {
+    static constexpr int N = N_, M = N_ / 2, R1 = R1_, R2 = R2_, R3 = R3_, L = L_;
+    static constexpr int P = M / L;                  // complex values per lane
+    static constexpr int U1 = P / R1, U2 = P / R2, U3 = P / R3;
+    static constexpr int S1 = S1_, AX = AX_, AY = AY_, AZ = AZ_;
+    static constexpr int SUB = 64 / L;               // frames per wavefront
+    static constexpr int WPB = WPB_;                 // wavefronts per workgroup
+    static constexpr int TPB = WPB * SUB;            // frames per workgroup per iteration
+    static constexpr bool REGT = REGT_;              // keep window + twiddle tables in registers
+    static constexpr int e1max = (R1 - 1) * S1 + M / R1;
+    static constexpr int e2max = (R1 - 1) * AX + (R2 - 1) * AY + (R3 - 1) * AZ + 1;
+    static constexpr int raw = e1max > e2max ? (e1max > M + 1 ? e1max : M + 1) : (e2max > M + 1 ? e2max : M + 1);
+    static constexpr int LDS_ELEMS = (raw + 1) & ~1;  // float2 elements per frame slot, 16-byte multiple
+    static constexpr int LDS_BYTES = LDS_ELEMS * 8 * TPB;
+    static_assert(R1 * R2 * R3 == M, "radices");
+    static_assert(P % R1 == 0 && P % R2 == 0 && P % R3 == 0, "each lane owns whole butterflies");
+};
+
+using Cfg512 = Cfg<512, 8, 8, 4, 32, 36, 4, 33, 1, 4, true>;
+using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 4, true>;
+using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, false>;
+using Cfg4096 = Cfg<4096, 8, 16, 16, 64, 272, 272, 17, 1, 4, false>;
+using Cfg8192 = Cfg<8192, 16, 16, 16, 64, 272, 272, 17, 1, 2, false>;
+
+struct StftKArgs {
+    const float* in;
+    long long in_pitch;
+    int channels;
+    int hop, feedblocks;
+    int mixop;           // 0 sum (AbsMean), 1 max, 2 min
+    int c_begin, c_end;  // channel range that is combined into one column
+    int per_channel;     // one column per (channel, frame)
+    int linear;          // store linear power instead of dB
+    float inv_div;       // AbsMean: the divisor (float(C)); others: 1
+    long long first_frame, n_frames, n_tasks;
+    float* out;
+    long long out_pitch, out_cpitch;
+    int ring_w, ring_pos;
+    int iters;
+    const float2* tab;   // [4][P][64]: window pairs, stage-1 twiddles, stage-2 twiddles, post-pass twiddles
+};
+
+// dB = 10*log10(p + 1e-11f) -- reference Spectrogram.cpp:107 with g_minValForLogSpectrogram (:36).
+// v_log_f32 (log2, 1 ulp) times 10*log10(2) split hi/lo; inputs are >= 1e-11, never denormal.
+__device__ __forceinline__ float to_db(float p) {
+    const float l2 = __builtin_amdgcn_logf(p + 1e-11f);
+    constexpr float kHi = 3.0102999566398120f;                       // float(10*log10(2))
+    constexpr float kLo = (float)(3.010299956639811952137 - (double)kHi);
+    return __builtin_fmaf(l2, kHi, l2 * kLo);
+}
+
+template <class C>
+__global__ __launch_bounds__(C::WPB * 64) void stft_db_kernel(const StftKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int L = C::L, P = C::P, M = C::M, R1 = C::R1, R2 = C::R2, R3 = C::R3;
+    constexpr int U1 = C::U1, U2 = C::U2, U3 = C::U3;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int ll = lane % L;
+    const int sub = lane / L;
+    float2* lds = reinterpret_cast<float2*>(smem_raw) + (wave * C::SUB + sub) * C::LDS_ELEMS;
+
+    // XCD-aware block remap (bijective): blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD one
+    // contiguous range of frames so that the overlapped halves of neighbouring frames hit the same L2.
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = b & 7;
+    const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+
+    // loop-invariant lane constants
+    const float2* tWin = a.tab + lane;
+    const float2* tTw1 = tWin + P * 64;
+    const float2* tTw2 = tTw1 + P * 64;
+    const float2* tPost = tTw2 + P * 64;
+    float2 rWin[C::REGT ? P : 1], rTw1[C::REGT ? P : 1], rTw2[C::REGT ? P : 1], rPost[C::REGT ? P : 1];
+    if constexpr (C::REGT) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            rWin[j] = tWin[j * 64];
+            rTw1[j] = tTw1[j * 64];
+            rTw2[j] = tTw2[j * 64];
+            rPost[j] = tPost[j * 64];
+        }
+    }
+#define JSG_WIN(j) (C::REGT ? rWin[C::REGT ? (j) : 0] : tWin[(j) * 64])
+#define JSG_TW1(j) (C::REGT ? rTw1[C::REGT ? (j) : 0] : tTw1[(j) * 64])
+#define JSG_TW2(j) (C::REGT ? rTw2[C::REGT ? (j) : 0] : tTw2[(j) * 64])
+#define JSG_POST(j) (C::REGT ? rPost[C::REGT ? (j) : 0] : tPost[(j) * 64])
+
+    // per-lane LDS element offsets of the two exchanges
+    int e1r[U2], e2w[U2], e2r[U3];
+#pragma unroll
+    for (int v = 0; v < U2; ++v) {
+        const int t2 = ll + L * v;
+        e1r[v] = (t2 / R3) * C::S1 + (t2 % R3);
+        e2w[v] = (t2 / R3) * C::AX + (t2 % R3) * C::AZ;
+    }
+#pragma unroll
+    for (int w = 0; w < U3; ++w) {
+        const int t3 = ll + L * w;
+        e2r[w] = (t3 % R1) * C::AX + (t3 / R1) * C::AY;
+    }
+
+    for (int it = 0; it < a.iters; ++it) {
+        long long task = ((long long)lb * a.iters + it) * C::TPB + wave * C::SUB + sub;
+        const bool valid = task < a.n_tasks;
+        if (task >= a.n_tasks) task = a.n_tasks - 1;   // keep the lanes busy with a duplicate; stores are masked
+        long long jj;        // frame index inside this launch
+        int c0, c1;
+        if (a.per_channel) {
+            const int ch = (int)(task / a.n_frames);
+            jj = task - (long long)ch * a.n_frames;
+            c0 = ch;
+            c1 = ch + 1;
+        } else {
+            jj = task;
+            c0 = a.c_begin;
+            c1 = a.c_end;
+        }
+        const long long j = a.first_frame + jj;
+        const long long start = (j / a.feedblocks) * (long long)C::N + (j % a.feedblocks) * (long long)a.hop;
+
+        float acc[P];
+        float accNy = 0.f;
+        const float init = (a.mixop == 2) ? 1000000.0f : 0.0f;   // reference Spectrogram.cpp:69,78,86
+#pragma unroll
+        for (int m = 0; m < P; ++m) acc[m] = init;
+        accNy = init;
+
+        for (int c = c0; c < c1; ++c) {
+            // ---- load the frame (each lane: P pairs of consecutive samples) and apply the window ----
+            const f2u* src = reinterpret_cast<const f2u*>(a.in + (long long)c * a.in_pitch + start) + ll;
+            float2 x[P];
+#pragma unroll
+            for (int m = 0; m < P; ++m) {
+                const f2u s = src[L * m];
+                const float2 w = JSG_WIN(m);
+                x[m] = make_float2(s.x * w.x, s.y * w.y);
+            }
+            // ---- stage 1: radix-R1 over n1, twiddle W_{R1R2}^{n2 k1}, exchange 1 ----
+#pragma unroll
+            for (int u = 0; u < U1; ++u) {
+                float2 t[R1];
+#pragma unroll
+                for (int n1 = 0; n1 < R1; ++n1) t[n1] = x[u + U1 * n1];
+                dft<R1>(t);
+                lds[ll + L * u] = t[0];
+#pragma unroll
+                for (int k1 = 1; k1 < R1; ++k1) lds[k1 * C::S1 + ll + L * u] = cmul(t[k1], JSG_TW1(u * R1 + k1));
+            }
+            wave_sync();
+            // ---- stage 2: radix-R2 over n2, twiddle W_M^{n3 (k1 + R1 k2)}, exchange 2 ----
+#pragma unroll
+            for (int v = 0; v < U2; ++v) {
+#pragma unroll
+                for (int n2 = 0; n2 < R2; ++n2) x[v * R2 + n2] = lds[e1r[v] + n2 * R3];
+            }
+            wave_sync();
+#pragma unroll
+            for (int v = 0; v < U2; ++v) {
+                float2 t[R2];
+#pragma unroll
+                for (int n2 = 0; n2 < R2; ++n2) t[n2] = x[v * R2 + n2];
+                dft<R2>(t);
+#pragma unroll
+                for (int k2 = 0; k2 < R2; ++k2) lds[e2w[v] + k2 * C::AY] = cmul(t[k2], JSG_TW2(v * R2 + k2));
+            }
+            wave_sync();
+            // ---- stage 3: radix-R3 over n3; Z[k], k = t3 + R1 R2 k3 ----
+#pragma unroll
+            for (int w = 0; w < U3; ++w) {
+#pragma unroll
+                for (int n3 = 0; n3 < R3; ++n3) x[w * R3 + n3] = lds[e2r[w] + n3 * C::AZ];
+            }
+            wave_sync();
+            float2 zp[P];
+#pragma unroll
+            for (int w = 0; w < U3; ++w) {
+                float2 t[R3];
+#pragma unroll
+                for (int n3 = 0; n3 < R3; ++n3) t[n3] = x[w * R3 + n3];
+                dft<R3>(t);
+#pragma unroll
+                for (int k3 = 0; k3 < R3; ++k3) {
+                    x[w * R3 + k3] = t[k3];
+                    lds[ll + L * w + R1 * R2 * k3] = t[k3];
+                }
+            }
+            if (ll == 0) lds[M] = x[0];   // Z[M] := Z[0]
+            wave_sync();
+            // ---- real-split post pass: X[k] = (Z[k] + conj Z[M-k])/2 - i/2 W_N^k (Z[k] - conj Z[M-k]) ----
+#pragma unroll
+            for (int w = 0; w < U3; ++w) {
+#pragma unroll
+                for (int k3 = 0; k3 < R3; ++k3) zp[w * R3 + k3] = lds[M - (ll + L * w + R1 * R2 * k3)];
+            }
+            wave_sync();   // the next FFT's exchange-1 stores must stay behind these loads
+#pragma unroll
+            for (int m = 0; m < P; ++m) {
+                const float2 z = x[m], p = zp[m];
+                const float2 S = make_float2(z.x + p.x, z.y - p.y);
+                const float2 D = make_float2(z.x - p.x, z.y + p.y);
+                const float2 W = JSG_POST(m);
+                const float xr = 0.5f * S.x + (W.x * D.x - W.y * D.y);
+                const float xi = 0.5f * S.y + (W.x * D.y + W.y * D.x);
+                const float pw = xr * xr + xi * xi;
+                if (a.mixop == 0) acc[m] += pw;
+                else if (a.mixop == 1) acc[m] = pw > acc[m] ? pw : acc[m];
+                else acc[m] = pw < acc[m] ? pw : acc[m];
+            }
+            {   // Nyquist bin X[M] = Re Z0 - Im Z0 (only lane 0 of the frame holds Z[0] in x[0])
+                const float d = x[0].x - x[0].y;
+                const float pw = d * d;
+                if (a.mixop == 0) accNy += pw;
+                else if (a.mixop == 1) accNy = pw > accNy ? pw : accNy;
+                else accNy = pw < accNy ? pw : accNy;
+            }
+        }
+
+        // ---- mix epilogue + dB + ring store ----
+        const long long col = (a.ring_pos + jj) % a.ring_w;
+        float* dst = a.out + col * a.out_pitch + (a.per_channel ? (long long)c0 * a.out_cpitch : 0ll);
+        const bool divide = a.inv_div != 1.0f;
+        if (valid) {
+#pragma unroll
+            for (int w = 0; w < U3; ++w) {
+#pragma unroll
+                for (int k3 = 0; k3 < R3; ++k3) {
+                    float pw = acc[w * R3 + k3];
+                    if (divide) pw = pw / a.inv_div;     // m_powerfinal[kk] /= m_channels (IEEE divide)
+                    dst[ll + L * w + R1 * R2 * k3] = a.linear ? pw : to_db(pw);
+                }
+            }
+            if (ll == 0) {
+                float pw = accNy;
+                if (divide) pw = pw / a.inv_div;
+                dst[M] = a.linear ? pw : to_db(pw);
+            }
+        }
+    }
+#undef JSG_WIN
+#undef JSG_TW1
+#undef JSG_TW2
+#undef JSG_POST
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// colour loop
+// ------------------------------------------------------------------------------------------------------------
+struct CmapKArgs {
+    const float* db;
+    long long db_pitch;
+    int ring_w, height, col_first, n_cols, x_first, x_wrap;
+    const int* lut;
+    int n_colors;
+    float vmin, vmax, top, mult;
+    unsigned* argb;
+    long long argb_pitch;
+    unsigned char* index;
+    long long index_pitch;
+};
+
+// CColorPalette::getRGBColor's index (reference CColorpalette.h:34-45), float32 arithmetic, truncation.
+__device__ __forceinline__ int color_index(float v, float vmin, float vmax, float top, float mult, int n_colors) {
+    if (v >= vmax) v = top;          // value = m_Max*0.9999f
+    if (v < vmin) v = vmin;
+    int idx = (int)((v - vmin) * mult);
+    return idx < n_colors ? idx : n_colors - 1;
+}
+
+constexpr int CM_TILE = 64;   // 64 columns x 64 bins per workgroup
+
+__global__ __launch_bounds__(256) void colormap_kernel(const CmapKArgs a) {
+    __shared__ int s_lut[1024];
+    __shared__ unsigned short s_idx[CM_TILE][CM_TILE + 2];   // [bin][col]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool lut_in_lds = a.n_colors <= 1024;
+    if (lut_in_lds)
+        for (int i = tid; i < a.n_colors; i += 256) s_lut[i] = a.lut[i];
+
+    const int col0 = blockIdx.x * CM_TILE;   // first column (relative to col_first) of this tile
+    const int bin0 = blockIdx.y * CM_TILE;
+    // read phase: each wave takes 16 columns; lane = bin (256 B coalesced per column)
+    const int bin = bin0 + lane;
+    for (int cc = wave; cc < CM_TILE; cc += 4) {
+        const int i = col0 + cc;
+        int idx = 0;
+        if (i < a.n_cols && bin < a.height) {
+            int col = a.col_first + i;
+            col %= a.ring_w;
+            const float v = a.db[(long long)col * a.db_pitch + bin];
+            idx = color_index(v, a.vmin, a.vmax, a.top, a.mult, a.n_colors);
+        }
+        s_idx[lane][cc] = (unsigned short)idx;
+    }
+    __syncthreads();
+    // write phase: each wave takes 16 image rows; lane = column (256 B coalesced per row when x does not wrap)
+    const int i = col0 + lane;
+    int x = a.x_first + i;
+    x %= a.x_wrap;
+    for (int rr = wave; rr < CM_TILE; rr += 4) {
+        const int bb = bin0 + rr;
+        if (i < a.n_cols && bb < a.height) {
+            const int idx = s_idx[rr][lane];
+            const long long y = a.height - 1 - bb;          // low frequencies at the bottom (Spectrogram.cpp:642)
+            if (a.argb) {
+                const int rgb = lut_in_lds ? s_lut[idx] : a.lut[idx];
+                a.argb[y * a.argb_pitch + x] = (unsigned)rgb | 0xFF000000u;   // Spectrogram.cpp:637
+            }
+            if (a.index) a.index[y * a.index_pitch + x] = (unsigned char)idx;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void db_from_power_kernel(const float* p, float* out,
+                                                            long long count, float divisor) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        float v = p[i];
+        if (divisor != 1.0f) v = v / divisor;
+        out[i] = to_db(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// plan: window + twiddle tables, laid out [table][register j][lane]
+// ------------------------------------------------------------------------------------------------------------
+template <class C>
+static void fill_tables(std::vector<float2>& t, const float* window, double amp) {
+    constexpr int L = C::L, P = C::P, R1 = C::R1, R2 = C::R2, R3 = C::R3, M = C::M, N = C::N;
+    t.assign(size_t(4) * P * 64, make_float2(0.f, 0.f));
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int lane = 0; lane < 64; ++lane) {
+        const int ll = lane % L;
+        for (int m = 0; m < P; ++m) {   // window pairs: samples 2n, 2n+1 with n = ll + L m
+            const int n = ll + L * m;
+            t[(0 * P + m) * 64 + lane] = make_float2(float(double(window[2 * n]) * amp), float(double(window[2 * n + 1]) * amp));
+        }
+        for (int u = 0; u < C::U1; ++u)
+            for (int k1 = 0; k1 < R1; ++k1) {
+                const int t1 = ll + L * u, n2 = t1 / R3;
+                const double ang = -two_pi * double((long long)n2 * k1 % (R1 * R2)) / double(R1 * R2);
+                t[(1 * P + u * R1 + k1) * 64 + lane] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
+            }
+        for (int v = 0; v < C::U2; ++v)
+            for (int k2 = 0; k2 < R2; ++k2) {
+                const int t2 = ll + L * v, k1 = t2 / R3, n3 = t2 % R3;
+                const double ang = -two_pi * double((long long)n3 * (k1 + R1 * k2) % M) / double(M);
+                t[(2 * P + v * R2 + k2) * 64 + lane] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
+            }
+        for (int w = 0; w < C::U3; ++w)
+            for (int k3 = 0; k3 < R3; ++k3) {
+                const int k = ll + L * w + R1 * R2 * k3;
+                const double ang = -two_pi * double(k) / double(N);
+                // -i/2 * exp(i ang) = 0.5 sin(ang) - 0.5 i cos(ang)
+                t[(3 * P + w * R3 + k3) * 64 + lane] = make_float2(float(0.5 * std::sin(ang)), float(-0.5 * std::cos(ang)));
+            }
+    }
+}
+
+template <class C>
+static hipError_t launch_stft(const StftKArgs& ka, int nblk, hipStream_t s) {
+    static bool attr_done[64] = {};
+    int dev = 0;
+    hipError_t err = hipGetDevice(&dev);
+    if (err != hipSuccess) return err;
+    if (C::LDS_BYTES > 48 * 1024 && dev < 64 && !attr_done[dev]) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_db_kernel<C>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (err != hipSuccess) return err;
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL(stft_db_kernel<C>, dim3(nblk), dim3(C::WPB * 64), C::LDS_BYTES, s, ka);
+    return hipGetLastError();
+}
+
+template <class C>
+static int tasks_per_block() { return C::TPB; }
+
+}  // namespace jsg
+
+using namespace jsg;
+
+struct jsg_plan {
+    int n = 0;
+    int device = -1;
+    float2* d_tab = nullptr;
+    size_t tab_elems = 0;
+};
+
+extern "C" {
+
+int jsg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int jsg_plan_create(jsg_plan** out, int n, const float* window, float power_scale) {
+    if (!out || !window) return jsg_fail(JSG_ERR_INVALID, "jsg_plan_create: null argument");
+    *out = nullptr;
+    if (!(power_scale > 0.f)) return jsg_fail(JSG_ERR_INVALID, "jsg_plan_create: power_scale must be > 0");
+    std::vector<float2> t;
+    const double amp = std::sqrt(double(power_scale));   // |FFT(a w x)|^2 = a^2 |FFT(w x)|^2
+    switch (n) {
+        case 512: fill_tables<Cfg512>(t, window, amp); break;
+        case 1024: fill_tables<Cfg1024>(t, window, amp); break;
+        case 2048: fill_tables<Cfg2048>(t, window, amp); break;
+        case 4096: fill_tables<Cfg4096>(t, window, amp); break;
+        case 8192: fill_tables<Cfg8192>(t, window, amp); break;
+        default:
+            return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_plan_create: FFT size must be 512, 1024, 2048, 4096 or 8192");
+    }
+    jsg_plan* p = new (std::nothrow) jsg_plan();
+    if (!p) return jsg_fail(JSG_ERR_NOMEM, "jsg_plan_create: out of host memory");
+    p->n = n;
+    p->tab_elems = t.size();
+    if (hipGetDevice(&p->device) != hipSuccess) {
+        delete p;
+        return jsg_fail(JSG_ERR_NO_DEVICE, "jsg_plan_create: no HIP device (the engine has no CPU fallback)");
+    }
+    hipError_t err = hipMalloc(reinterpret_cast<void**>(&p->d_tab), t.size() * sizeof(float2));
+    if (err == hipSuccess) err = hipMemcpy(p->d_tab, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice);
+    if (err != hipSuccess) {
+        if (p->d_tab) (void)hipFree(p->d_tab);
+        delete p;
+        return jsg_fail_hip(err, "jsg_plan_create");
+    }
+    *out = p;
+    return JSG_OK;
+}
+
+int jsg_plan_destroy(jsg_plan* plan) {
+    if (!plan) return JSG_OK;
+    if (plan->d_tab) (void)hipFree(plan->d_tab);
+    delete plan;
+    return JSG_OK;
+}
+
+int jsg_plan_fft_size(const jsg_plan* plan) { return plan ? plan->n : JSG_ERR_INVALID; }
+
+int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* stream) {
+    if (!plan || !g) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: null argument");
+    if (g->n_frames == 0) return JSG_OK;
+    const int H = plan->n / 2 + 1;
+    if (!g->in || !g->out_db || g->channels <= 0 || g->hop <= 0 || g->feedblocks <= 0 || g->n_frames < 0 ||
+        g->first_frame < 0 || g->ring_width <= 0 || g->ring_pos < 0 || g->ring_pos >= g->ring_width ||
+        g->out_pitch < H)
+        return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: bad geometry");
+    StftKArgs ka{};
+    ka.in = g->in;
+    ka.in_pitch = g->in_pitch;
+    ka.channels = g->channels;
+    ka.hop = g->hop;
+    ka.feedblocks = g->feedblocks;
+    ka.first_frame = g->first_frame;
+    ka.n_frames = g->n_frames;
+    ka.out = g->out_db;
+    ka.out_pitch = g->out_pitch;
+    ka.out_cpitch = g->out_channel_pitch;
+    ka.ring_w = g->ring_width;
+    ka.ring_pos = g->ring_pos;
+    ka.tab = plan->d_tab;
+    ka.per_channel = 0;
+    ka.c_begin = 0;
+    ka.c_end = g->channels;
+    ka.inv_div = 1.0f;
+    ka.mixop = 0;
+    switch (g->mix_mode) {
+        case JSG_MIX_ABSMEAN: ka.inv_div = float(g->channels); break;
+        case JSG_MIX_MAX: ka.mixop = 1; break;
+        case JSG_MIX_MIN: ka.mixop = 2; break;
+        case JSG_MIX_LEFT: ka.c_end = 1; break;
+        case JSG_MIX_RIGHT:
+            // reference Spectrogram.cpp:97-105 reads m_power[1] whenever m_channels > 0; with one channel that is
+            // out of bounds there, so it is rejected here
+            if (g->channels < 2) return jsg_fail(JSG_ERR_INVALID, "JSG_MIX_RIGHT needs at least two channels");
+            ka.c_begin = 1;
+            ka.c_end = 2;
+            break;
+        case JSG_MIX_PER_CHANNEL: ka.per_channel = 1; break;
+        case JSG_MIX_SUM: break;
+        default: return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: unknown mix mode");
+    }
+    ka.linear = g->linear_out ? 1 : 0;
+    ka.n_tasks = ka.per_channel ? g->n_frames * g->channels : g->n_frames;
+    int tpb = 0;
+    switch (plan->n) {
+        case 512: tpb = Cfg512::TPB; break;
+        case 1024: tpb = Cfg1024::TPB; break;
+        case 2048: tpb = Cfg2048::TPB; break;
+        case 4096: tpb = Cfg4096::TPB; break;
+        case 8192: tpb = Cfg8192::TPB; break;
+    }
+    const long long want = (ka.n_tasks + tpb - 1) / tpb;
+    const long long max_blocks = 256ll * 16;   // a few resident workgroups per CU; the rest is looped over
+    const int nblk = int(want < max_blocks ? want : max_blocks);
+    ka.iters = int((ka.n_tasks + (long long)nblk * tpb - 1) / ((long long)nblk * tpb));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipError_t err = hipSuccess;
+    switch (plan->n) {
+        case 512: err = launch_stft<Cfg512>(ka, nblk, s); break;
+        case 1024: err = launch_stft<Cfg1024>(ka, nblk, s); break;
+        case 2048: err = launch_stft<Cfg2048>(ka, nblk, s); break;
+        case 4096: err = launch_stft<Cfg4096>(ka, nblk, s); break;
+        case 8192: err = launch_stft<Cfg8192>(ka, nblk, s); break;
+    }
+    if (err != hipSuccess) return jsg_fail_hip(err, "jsg_stft_db_launch");
+    return JSG_OK;
+}
+
+int jsg_db_from_power_launch(const float* power, float* out, int64_t count, float divisor, void* stream) {
+    if (count == 0) return JSG_OK;
+    if (!power || !out || count < 0 || !(divisor > 0.f)) return jsg_fail(JSG_ERR_INVALID, "jsg_db_from_power_launch: bad argument");
+    const long long blocks = (count + 255) / 256;
+    hipLaunchKernelGGL(db_from_power_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), power, out, (long long)count, divisor);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return jsg_fail_hip(err, "jsg_db_from_power_launch");
+    return JSG_OK;
+}
+
+int jsg_colormap_launch(const jsg_colormap_args* g, void* stream) {
+    if (!g) return jsg_fail(JSG_ERR_INVALID, "jsg_colormap_launch: null argument");
+    if (g->n_cols == 0) return JSG_OK;
+    if (!g->db || !g->lut || g->height <= 0 || g->ring_width <= 0 || g->n_cols < 0 || g->x_wrap <= 0 ||
+        g->n_colors <= 0 || g->col_first < 0 || g->x_first < 0 || (!g->argb_out && !g->index_out))
+        return jsg_fail(JSG_ERR_INVALID, "jsg_colormap_launch: bad geometry");
+    if (g->index_out && g->n_colors > 256)
+        return jsg_fail(JSG_ERR_INVALID, "jsg_colormap_launch: the 8-bit index plane needs n_colors <= 256");
+    if (g->n_colors > 65535) return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_colormap_launch: n_colors > 65535");
+    CmapKArgs ka{};
+    ka.db = g->db;
+    ka.db_pitch = g->db_pitch;
+    ka.ring_w = g->ring_width;
+    ka.height = g->height;
+    ka.col_first = g->col_first % g->ring_width;
+    ka.n_cols = g->n_cols;
+    ka.x_first = g->x_first % g->x_wrap;
+    ka.x_wrap = g->x_wrap;
+    ka.lut = g->lut;
+    ka.n_colors = g->n_colors;
+    ka.vmin = g->vmin;
+    ka.vmax = g->vmax;
+    ka.top = g->vmax * 0.9999f;
+    ka.mult = g->access_mult;
+    ka.argb = g->argb_out;
+    ka.argb_pitch = g->argb_pitch;
+    ka.index = g->index_out;
+    ka.index_pitch = g->index_pitch;
+    dim3 grid((g->n_cols + CM_TILE - 1) / CM_TILE, (g->height + CM_TILE - 1) / CM_TILE);
+    hipLaunchKernelGGL(colormap_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ka);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return jsg_fail_hip(err, "jsg_colormap_launch");
+    return JSG_OK;
+}
+
+}  // extern "C"

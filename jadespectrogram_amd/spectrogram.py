@@ -1,0 +1,291 @@
+"""Python mirror of the reference's host interface for the hot path, on top of the C-ABI (include/jsg.h).
+
+    Spectrogram          <-> class Spectrogram          (reference Spectrogram.h:81-169)   method names kept
+    CColorPalette        <-> class CColorPalette        (reference CColorpalette.h:6-61)
+    SpectrogramDisplay   <-> the colour half of SpectrogramComponent::timerCallback (Spectrogram.cpp:590-731)
+    Plan / stft_db / colormap : the stateless device ops on torch tensors that live in HBM (used by bench.py)
+
+Everything computes on the GPU through libjsg.so; numpy/torch are used for buffers only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import JsgError, check, lib
+
+
+# --------------------------------------------------------------------------------------------------
+# host-side precompute (same arithmetic as the reference, done in the library)
+# --------------------------------------------------------------------------------------------------
+def feed_samples(feed_percent: float, fftsize: int) -> int:
+    return check(lib().jsg_feed_samples(feed_percent, fftsize))
+
+
+def memsize_blocks(memsize_s: float, fs: float, hop: int) -> int:
+    return check(lib().jsg_memsize_blocks(memsize_s, fs, hop))
+
+
+def next_power_of_2(ms: float, fs: float) -> int:
+    return check(lib().jsg_next_power_of_2(ms, fs))
+
+
+def window(kind: int, n: int) -> np.ndarray:
+    out = np.zeros(n, dtype=np.float32)
+    check(lib().jsg_window_build(kind, n, out.ctypes.data))
+    return out
+
+
+def colormap_lut(n_colors: int, scheme: int) -> np.ndarray:
+    out = np.zeros(n_colors, dtype=np.int32)
+    check(lib().jsg_colormap_build(n_colors, scheme, out.ctypes.data))
+    return out
+
+
+def colormap_range(n_colors: int, lo: float, hi: float):
+    a, b, m = C.c_float(), C.c_float(), C.c_float()
+    check(lib().jsg_colormap_range(n_colors, lo, hi, C.byref(a), C.byref(b), C.byref(m)))
+    return np.float32(a.value), np.float32(b.value), np.float32(m.value)
+
+
+# --------------------------------------------------------------------------------------------------
+# class Spectrogram
+# --------------------------------------------------------------------------------------------------
+class Spectrogram:
+    """Drop-in mirror of the reference's `Spectrogram` (engine half).  The channel count is explicit."""
+
+    ChannelMixMode = type("ChannelMixMode", (), dict(AbsMean=0, Max=1, Min=2, Left=3, Right=4, PerChannel=100))
+    Windows = type("Windows", (), dict(Rect=0, Hann=1, Hamming=2, BlackmanHarris=3, FlatTop=4, HannPoisson=5))
+    FeedPercentage = type("FeedPercentage", (), dict(perc100=0, perc50=1, perc25=2, perc10=3))
+
+    def __init__(self, channels: int = 2):
+        self._h = C.c_void_p()
+        check(lib().jsg_create(C.byref(self._h), int(channels)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().jsg_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _c(self, rc):
+        return check(rc, self._h)
+
+    # setters (Spectrogram.h:116-123)
+    def setSamplerate(self, fs): self._c(lib().jsg_set_samplerate(self._h, fs))
+    def setchannels(self, c): self._c(lib().jsg_set_channels(self._h, int(c)))
+    def setFFTSize(self, n): self._c(lib().jsg_set_fft_size(self._h, int(n)))
+    def setclosestFFTSize_ms(self, ms): self._c(lib().jsg_set_closest_fft_size_ms(self._h, ms))
+    def setmemoryTime_s(self, s): self._c(lib().jsg_set_memory_time_s(self._h, s))
+    def setfeed_percent(self, feed): self._c(lib().jsg_set_feed_percent(self._h, int(feed)))
+    def setfeed_percent_ext(self, pct): self._c(lib().jsg_set_feed_percent_ext(self._h, pct))
+    def setPauseMode(self, mode): self._c(lib().jsg_set_pause_mode(self._h, int(bool(mode))))
+    def setWindow(self, win): self._c(lib().jsg_set_window(self._h, int(win)))
+    def setMixMode(self, mode): self._c(lib().jsg_set_mix_mode(self._h, int(mode)))
+    def setPowerScale(self, s): self._c(lib().jsg_set_power_scale(self._h, s))
+
+    def setWindowTable(self, w):
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        self._c(lib().jsg_set_window_table(self._h, w.ctypes.data, w.size))
+
+    def getnextpowerof2(self, ms): return next_power_of_2(ms, self.getSamplerate())
+    def getSpectrumSize(self): return lib().jsg_get_spectrum_size(self._h)
+    def getMemorySize(self): return lib().jsg_get_memory_size(self._h)
+    def getSamplerate(self): return lib().jsg_get_samplerate(self._h)
+    def getFFTSize(self): return lib().jsg_get_fft_size(self._h)
+    def getFeedSamples(self): return lib().jsg_get_feed_samples(self._h)
+    def getFeedBlocks(self): return lib().jsg_get_feedblocks(self._h)
+    def getChannels(self): return lib().jsg_get_channels(self._h)
+
+    def getWindow(self):
+        w = np.zeros(self.getFFTSize(), dtype=np.float32)
+        self._c(lib().jsg_get_window(self._h, w.ctypes.data, w.size))
+        return w
+
+    def processSynchronBlock(self, data, midi=None) -> int:
+        """data: [channels][fft size] float32 (reference: vector<vector<float>>&, Spectrogram.cpp:37)."""
+        data = np.ascontiguousarray(data, dtype=np.float32)
+        n, ch = self.getFFTSize(), self.getChannels()
+        if data.shape != (ch, n):
+            raise JsgError(capi.JSG_ERR_SIZE_MISMATCH, f"block must be [{ch}][{n}], got {data.shape}")
+        ptrs = (C.c_void_p * ch)(*[data[c].ctypes.data for c in range(ch)])
+        return self._c(lib().jsg_process_block(self._h, ptrs))
+
+    def processBlocks(self, samples) -> int:
+        """samples: [channels][K * fft size]; the same as K processSynchronBlock calls, one kernel launch."""
+        samples = np.ascontiguousarray(samples, dtype=np.float32)
+        n, ch = self.getFFTSize(), self.getChannels()
+        if samples.ndim != 2 or samples.shape[0] != ch or samples.shape[1] % n:
+            raise JsgError(capi.JSG_ERR_SIZE_MISMATCH, "samples must be [channels][K*fftsize]")
+        return self._c(lib().jsg_process_blocks(self._h, samples.ctypes.data, samples.shape[1], samples.shape[1] // n))
+
+    def processBlocksDevice(self, d_samples) -> int:
+        """d_samples: torch float32 CUDA tensor [channels][K * fft size] already resident in HBM."""
+        n, ch = self.getFFTSize(), self.getChannels()
+        assert d_samples.is_cuda and d_samples.dtype.is_floating_point and d_samples.element_size() == 4
+        assert d_samples.dim() == 2 and d_samples.shape[0] == ch and d_samples.shape[1] % n == 0
+        assert d_samples.stride(1) == 1
+        return self._c(lib().jsg_process_blocks_device(self._h, d_samples.data_ptr(), d_samples.stride(0),
+                                                       d_samples.shape[1] // n))
+
+    def getMem(self, mem: np.ndarray):
+        """mem: caller's [W][H] float32 array, updated in place.  Returns (newVals, pos); newVals == -1 on a
+        size mismatch like the reference (Spectrogram.cpp:297-298)."""
+        if mem.dtype != np.float32 or not mem.flags.c_contiguous or mem.ndim != 2 or mem.shape[1] != self.getSpectrumSize():
+            return -1, None
+        pos = C.c_int(0)
+        rc = lib().jsg_get_mem(self._h, mem.ctypes.data, mem.shape[0], C.byref(pos))
+        if rc == capi.JSG_ERR_SIZE_MISMATCH:
+            return -1, None
+        self._c(rc)
+        return rc, pos.value
+
+    def ring_device(self):
+        p, pitch, w, pos = C.c_void_p(), C.c_int64(), C.c_int(), C.c_int()
+        self._c(lib().jsg_ring_device(self._h, C.byref(p), C.byref(pitch), C.byref(w), C.byref(pos)))
+        return p.value, pitch.value, w.value, pos.value
+
+    def sync(self): self._c(lib().jsg_sync(self._h))
+
+
+class SpectrogramDisplay:
+    """timerCallback's colour loop on the engine's device-resident ring (Spectrogram.cpp:590-731)."""
+
+    def __init__(self, spectrogram: Spectrogram, n_colors: int = 256, scheme: int = capi.CM_JADE):
+        self.spec = spectrogram
+        spectrogram._c(lib().jsg_display_set_colormap(spectrogram._h, n_colors, scheme))
+
+    def setColorSceme(self, scheme, n_colors: int = 256):
+        self.spec._c(lib().jsg_display_set_colormap(self.spec._h, n_colors, int(scheme)))
+
+    def setRunning(self, running: bool):
+        self.spec._c(lib().jsg_display_set_running(self.spec._h, int(bool(running))))
+
+    def invalidate(self):
+        self.spec._c(lib().jsg_display_invalidate(self.spec._h))
+
+    def timerCallback(self, img: np.ndarray, min_color=-50.0, max_color=50.0):
+        """img: [H][W] uint32 ARGB, updated in place.  Returns (newVals, pos)."""
+        assert img.dtype == np.uint32 and img.ndim == 2 and img.strides[1] == 4
+        nv, pos = C.c_int(), C.c_int()
+        self.spec._c(lib().jsg_display_update(self.spec._h, min_color, max_color, img.ctypes.data, img.strides[0] // 4,
+                                              C.byref(nv), C.byref(pos)))
+        return nv.value, pos.value
+
+
+class CColorPalette:
+    """Host mirror of the reference's CColorPalette: table + range on the host, bulk mapping on the GPU."""
+    kMono, kBW, kHot, kRainbow, kViridis, kPlasma, kJade = range(7)
+
+    def __init__(self, NrOfColors: int = 2, ColorScheme: int = 0):
+        self.m_NrOfColors, self.m_ColorScheme = int(NrOfColors), int(ColorScheme)
+        self.m_Color = colormap_lut(self.m_NrOfColors, self.m_ColorScheme)
+        self.m_Min, self.m_Max, self.m_AccessMult = colormap_range(self.m_NrOfColors, 0.0, 1.0)
+        self.m_Min, self.m_Max = np.float32(0.0), np.float32(1.0)
+
+    def setValueRange(self, Min, Max):
+        self.m_Min, self.m_Max, self.m_AccessMult = colormap_range(self.m_NrOfColors, Min, Max)
+
+    def setNrOfColors(self, n):
+        self.m_NrOfColors = int(n)
+        self.m_AccessMult = np.float32(self.m_NrOfColors) / np.float32(self.m_Max - self.m_Min)
+        self.m_Color = colormap_lut(self.m_NrOfColors, self.m_ColorScheme)
+
+    def setColorSceme(self, scheme):
+        self.m_ColorScheme = int(scheme)
+        self.m_Color = colormap_lut(self.m_NrOfColors, self.m_ColorScheme)
+
+
+# --------------------------------------------------------------------------------------------------
+# stateless device ops on torch tensors
+# --------------------------------------------------------------------------------------------------
+class Plan:
+    def __init__(self, n: int, window_table: np.ndarray, power_scale: float = 1.0):
+        w = np.ascontiguousarray(window_table, dtype=np.float32)
+        assert w.size == n
+        self._p = C.c_void_p()
+        check(lib().jsg_plan_create(C.byref(self._p), int(n), w.ctypes.data, power_scale))
+        self.n = int(n)
+
+    def close(self):
+        if getattr(self, "_p", None) is not None and self._p:
+            lib().jsg_plan_destroy(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def stft_db(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: int | None = None, mix_mode: int = 0,
+            first_frame: int = 0, ring_pos: int = 0, linear_out: bool = False, stream: int | None = None):
+    """Enqueue one fused STFT->dB launch.  d_in: torch CUDA float32 [C][samples]; d_out: [W][pitch] (or
+    [C][W][pitch] with mix_mode PER_CHANNEL).  Frame j starts at sample (j//feedblocks)*n + (j%feedblocks)*hop."""
+    import torch
+    assert d_in.is_cuda and d_in.dtype == torch.float32 and d_in.dim() == 2 and d_in.stride(1) == 1
+    assert d_out.is_cuda and d_out.dtype == torch.float32 and d_out.stride(-1) == 1
+    a = capi.StftArgs()
+    a.in_ = d_in.data_ptr()
+    a.in_pitch = d_in.stride(0)
+    a.channels = d_in.shape[0]
+    a.hop = hop
+    a.feedblocks = feedblocks if feedblocks is not None else max(1, plan.n // hop)
+    a.mix_mode = mix_mode
+    a.first_frame = first_frame
+    a.n_frames = n_frames
+    a.out_db = d_out.data_ptr()
+    a.out_pitch = d_out.stride(-2)
+    a.out_channel_pitch = d_out.stride(0) if d_out.dim() == 3 else 0
+    a.ring_width = d_out.shape[-2]
+    a.ring_pos = ring_pos
+    a.linear_out = int(bool(linear_out))
+    if stream is None:
+        stream = torch.cuda.current_stream(d_in.device).cuda_stream
+    check(lib().jsg_stft_db_launch(plan._p, C.byref(a), C.c_void_p(stream)))
+
+
+def colormap(d_db, d_lut, lo: float, hi: float, *, d_argb=None, d_index=None, col_first: int = 0, n_cols: int | None = None,
+             x_first: int = 0, height: int | None = None, stream: int | None = None):
+    """Enqueue the colour loop: d_db [W][pitch] float32 CUDA -> d_argb [H][Wimg] int32/uint32 and/or d_index uint8."""
+    import torch
+    a = capi.ColormapArgs()
+    a.db = d_db.data_ptr()
+    a.db_pitch = d_db.stride(0)
+    a.ring_width = d_db.shape[0]
+    a.height = height if height is not None else d_db.shape[1]
+    a.col_first = col_first
+    a.n_cols = n_cols if n_cols is not None else d_db.shape[0]
+    a.x_first = x_first
+    a.lut = d_lut.data_ptr()
+    a.n_colors = d_lut.numel()
+    a.vmin, a.vmax, a.access_mult = (float(v) for v in colormap_range(a.n_colors, lo, hi))
+    if d_argb is not None:
+        a.argb_out = d_argb.data_ptr()
+        a.argb_pitch = d_argb.stride(0)
+        a.x_wrap = d_argb.shape[1]
+    if d_index is not None:
+        a.index_out = d_index.data_ptr()
+        a.index_pitch = d_index.stride(0)
+        a.x_wrap = d_index.shape[1]
+    if stream is None:
+        stream = torch.cuda.current_stream(d_db.device).cuda_stream
+    check(lib().jsg_colormap_launch(C.byref(a), C.c_void_p(stream)))
+
+
+def db_from_power(d_power, d_out, divisor: float = 1.0, stream: int | None = None):
+    """out = 10*log10(power/divisor + 1e-11f) elementwise on the GPU (finishes a cross-GPU AbsMean)."""
+    import torch
+    assert d_power.is_cuda and d_power.dtype == torch.float32 and d_power.is_contiguous()
+    assert d_out.is_cuda and d_out.dtype == torch.float32 and d_out.is_contiguous() and d_out.numel() == d_power.numel()
+    if stream is None:
+        stream = torch.cuda.current_stream(d_power.device).cuda_stream
+    check(lib().jsg_db_from_power_launch(d_power.data_ptr(), d_out.data_ptr(), d_power.numel(), divisor, C.c_void_p(stream)))

@@ -1,0 +1,193 @@
+"""GPU parity: the HIP path (through the C-ABI) against the oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+from parity_util import assert_db_close, assert_power_close, mixed_power_f64
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    torch.cuda.set_device(0)
+    return torch
+
+
+def _padded(x, n):
+    return np.concatenate([np.zeros((x.shape[0], n), np.float32), x], axis=1)
+
+
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096, 8192])
+@pytest.mark.parametrize("kind", ["mix", "noise"])
+def test_linear_power_vs_float64_dft(jsg, oracle, torch_cuda, n, kind):
+    """|X|^2 of every frame against the float64 DFT of the float32 windowed frame (mono, Hann, 50 % hop)."""
+    torch = torch_cuda
+    hop, K = n // 2, 12
+    x = oracle.synth_audio(1, K * n, kind=kind)
+    win = oracle.window(oracle.WIN_HANN, n)
+    plan = jsg.Plan(n, win)
+    F = 2 * K
+    d_in = torch.from_numpy(_padded(x, n)).cuda()
+    d_out = torch.full((F, n // 2 + 1 + 7), -1.0, device="cuda")
+    jsg.stft_db(plan, d_in, hop, F, d_out, linear_out=True)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    assert (got[:, n // 2 + 1:] == -1.0).all(), "wrote outside the column"
+    ref = oracle.stft_db_reference(x, n, hop, 2, win, return_power=True)[0]
+    worst = assert_power_close(got[:, :n // 2 + 1], ref, f"n={n} {kind}")
+    assert worst < 1e-5, worst
+
+
+CASES = [
+    # n, feed, channels, mix, window
+    (1024, 1, 1, 0, 1),      # C1/C2: mono 1024 / 512 hop / Hann
+    (1024, 1, 2, 0, 1),      # the plugin's stereo bus
+    (2048, 2, 8, 0, 1),      # C3: 8 ch, 2048, 75 % overlap
+    (1024, 1, 8, 0, 3),      # C4 per-GPU shard, BlackmanHarris
+    (2048, 1, 2, 0, 1),      # the plugin's prepareToPlay defaults
+    (1024, 0, 2, 1, 0),      # Max, Rect, no overlap
+    (1024, 2, 3, 2, 2),      # Min, Hamming
+    (4096, 1, 2, 3, 4),      # Left, FlatTop
+    (512, 1, 2, 4, 5),       # Right, HannPoisson, two frames per wave
+    (8192, 1, 1, 0, 1),
+    (1024, 3, 2, 0, 1),      # perc10: irregular hop 102 x9 + 106
+    (2048, 3, 1, 0, 1),      # perc10 with an odd hop (205): 4-byte aligned pair loads
+    (512, 3, 1, 0, 1),
+]
+
+
+@pytest.mark.parametrize("n,feed,channels,mix,win", CASES)
+def test_engine_db_columns(jsg, oracle, n, feed, channels, mix, win):
+    K = 6
+    x = oracle.synth_audio(channels, K * n, seed=77)
+    s = jsg.Spectrogram(channels)
+    s.setSamplerate(48000.0); s.setmemoryTime_s(2.0); s.setFFTSize(n); s.setfeed_percent(feed)
+    s.setWindow(win); s.setMixMode(mix)
+    o = oracle.OracleSpectrogram(channels)
+    o.set_samplerate(48000.0); o.set_memory_time_s(2.0); o.set_fft_size(n); o.set_feed_percent(feed)
+    o.set_window(win); o.mode = mix
+    assert (s.getMemorySize(), s.getSpectrumSize(), s.getFeedSamples()) == (o.memsize_blocks, o.freqsize, o.hop)
+    assert (s.getWindow().view(np.uint32) == o.window.view(np.uint32)).all()
+    s.processBlocks(x)
+    mem = np.zeros((s.getMemorySize(), s.getSpectrumSize()), np.float32)
+    nv, pos = s.getMem(mem)
+    F = K * o.feedblocks
+    assert pos == F % o.memsize_blocks and nv == oracle.NEW_ENTRY_SENTINEL + F
+    ref = oracle.stft_db_reference(x, n, o.hop, o.feedblocks, o.window, mode=mix)
+    pw = mixed_power_f64(oracle, x, n, o.hop, o.feedblocks, o.window, mix)
+    assert (mem[0] == np.float32(-110.0)).all(), "first column of a fresh engine is the all-zero frame"
+    assert_db_close(mem[:F], ref, pw, f"n={n} feed={feed} C={channels} mix={mix} win={win}")
+    assert (mem[F:] == np.float32(-120.0)).all(), "untouched ring columns keep the -120 dB fill"
+    s.close()
+
+
+def test_per_channel_mode_equals_single_channel_engines(jsg, oracle):
+    C, n, K = 4, 1024, 4
+    x = oracle.synth_audio(C, K * n, seed=5)
+    s = jsg.Spectrogram(C)
+    s.setSamplerate(48000.0); s.setFFTSize(n); s.setfeed_percent(1); s.setMixMode(jsg.capi.MIX_PER_CHANNEL)
+    s.processBlocks(x)
+    W, H = s.getMemorySize(), s.getSpectrumSize()
+    mem = np.zeros((C * W, H), np.float32)
+    s.getMem(mem)
+    mem = mem.reshape(C, W, H)
+    for c in range(C):
+        m = jsg.Spectrogram(1)
+        m.setSamplerate(48000.0); m.setFFTSize(n); m.setfeed_percent(1)
+        m.processBlocks(x[c:c + 1])
+        one = np.zeros((W, H), np.float32)
+        m.getMem(one)
+        assert (one.view(np.uint32) == mem[c].view(np.uint32)).all(), "sharding by channel must be bit-identical"
+        m.close()
+    s.close()
+
+
+def test_block_by_block_stream_pause_and_getmem(jsg, oracle):
+    """processSynchronBlock per block with getMem in between, a pause, and more than one ring wrap."""
+    C, n = 2, 1024
+    s = jsg.Spectrogram(C); o = oracle.OracleSpectrogram(C)
+    for e in (s,):
+        e.setSamplerate(48000.0); e.setmemoryTime_s(0.25); e.setFFTSize(n); e.setfeed_percent(1)
+    o.set_samplerate(48000.0); o.set_memory_time_s(0.25); o.set_fft_size(n); o.set_feed_percent(1)
+    W, H = s.getMemorySize(), s.getSpectrumSize()
+    assert W == o.memsize_blocks == 23
+    x = oracle.synth_audio(C, 40 * n, seed=9)
+    mem_g = np.zeros((W, H), np.float32); mem_o = np.zeros((W, H), np.float32)
+    assert s.getMem(np.zeros((W + 1, H), np.float32))[0] == -1          # reference: size mismatch -> -1
+    for b in range(40):
+        if b == 10:
+            s.setPauseMode(True); o.set_pause_mode(True)
+        if b == 14:
+            s.setPauseMode(False); o.set_pause_mode(False)
+        blk = x[:, b * n:(b + 1) * n]
+        assert s.processSynchronBlock(blk) == 0
+        o.process_synchron_block(blk)
+        if b % 4 == 3 or b == 39:
+            nv_g, pos_g = s.getMem(mem_g)
+            nv_o, pos_o = o.get_mem(mem_o)
+            assert (nv_g, pos_g) == (nv_o, pos_o), b
+            d = np.abs(mem_g.astype(np.float64) - mem_o.astype(np.float64))
+            assert d.max() < 2e-3, (b, d.max())   # coarse here; exact tolerances are checked in test_engine_db_columns
+    # batch == block-by-block, bit for bit
+    s2 = jsg.Spectrogram(C)
+    s2.setSamplerate(48000.0); s2.setmemoryTime_s(0.25); s2.setFFTSize(n); s2.setfeed_percent(1)
+    s2.processBlocks(x[:, :10 * n]); s2.processBlocks(x[:, 14 * n:])
+    mem2 = np.zeros((W, H), np.float32)
+    s2.getMem(mem2)
+    full = np.zeros((W, H), np.float32)
+    o2 = jsg.Spectrogram(C)
+    o2.setSamplerate(48000.0); o2.setmemoryTime_s(0.25); o2.setFFTSize(n); o2.setfeed_percent(1)
+    for b in list(range(10)) + list(range(14, 40)):
+        o2.processSynchronBlock(x[:, b * n:(b + 1) * n])
+    o2.getMem(full)
+    assert (full.view(np.uint32) == mem2.view(np.uint32)).all()
+    for e in (s, s2, o2):
+        e.close()
+
+
+def test_silence_and_full_scale(jsg, oracle):
+    n = 1024
+    s = jsg.Spectrogram(1)
+    s.setSamplerate(48000.0); s.setFFTSize(n); s.setfeed_percent(1)
+    s.processBlocks(np.zeros((1, 4 * n), np.float32))
+    mem = np.zeros((s.getMemorySize(), 513), np.float32)
+    s.getMem(mem)
+    assert (mem[:8] == np.float32(-110.0)).all()        # 10*log10(1e-11f)
+    t = np.arange(4 * n)
+    x = np.sin(2 * np.pi * 1000.0 * t / 48000.0).astype(np.float32)[None]
+    s.processBlocks(x)
+    s.getMem(mem)
+    assert abs(mem[8 + 4, 21] - 51.7976) < 2e-3 and abs(mem[8 + 4, 22] - 49.8594) < 2e-3
+    s.close()
+
+
+def test_power_scale_and_custom_window(jsg, oracle):
+    n = 1024
+    x = oracle.synth_audio(1, 4 * n, seed=3)
+    s = jsg.Spectrogram(1)
+    s.setSamplerate(48000.0); s.setFFTSize(n); s.setfeed_percent(1); s.setPowerScale(1.0 / n)
+    s.processBlocks(x)
+    mem = np.zeros((s.getMemorySize(), 513), np.float32); s.getMem(mem)
+    win = oracle.window(1, n)
+    ref = oracle.stft_db_reference(x, n, 512, 2, win, power_scale=1.0 / n)
+    pw = mixed_power_f64(oracle, x, n, 512, 2, win, 0, power_scale=1.0 / n)
+    assert_db_close(mem[:8], ref, pw, "power_scale 1/N")
+    w2 = (win * np.linspace(0.5, 1.5, n)).astype(np.float32)
+    s.setPowerScale(1.0); s.setFFTSize(n); s.setfeed_percent(1); s.setWindowTable(w2)
+    s.processBlocks(x); s.getMem(mem)
+    ref = oracle.stft_db_reference(x, n, 512, 2, w2)
+    pw = mixed_power_f64(oracle, x, n, 512, 2, w2, 0)
+    assert_db_close(mem[:8], ref, pw, "custom window")
+    s.close()
+
+
+def test_unsupported_sizes_fail_loudly(jsg):
+    s = jsg.Spectrogram(1)
+    with pytest.raises(jsg.JsgError) as ei:
+        s.setFFTSize(1000)
+    assert ei.value.code == jsg.capi.JSG_ERR_UNSUPPORTED
+    with pytest.raises(jsg.JsgError):
+        s.setMixMode(4)     # Right with one channel: out-of-bounds read in the reference
+    s.close()

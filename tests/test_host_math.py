@@ -1,0 +1,86 @@
+"""libjsg.so's host-side precompute (windows, geometry, colour tables) and the C-ABI surface.  CPU only:
+nothing here touches a GPU; the compute entry points must refuse to run without one."""
+import os
+import re
+
+import numpy as np
+
+
+def test_library_exports_every_declared_symbol(jsg):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "jsg.h")).read()
+    declared = set(re.findall(r"\b(jsg_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 45
+    lib = jsg.capi.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libjsg.so does not export {name}"
+    assert declared == set(jsg.capi.SIGNATURES), declared ^ set(jsg.capi.SIGNATURES)
+    assert lib.jsg_abi_version() == 1
+
+
+def test_windows_bit_exact_vs_oracle(jsg, oracle):
+    for kind in range(6):
+        for n in (512, 1024, 2048, 4096, 8192):
+            a, b = jsg.window(kind, n), oracle.window(kind, n)
+            assert (a.view(np.uint32) == b.view(np.uint32)).all(), (kind, n)
+
+
+def test_geometry_vs_oracle_and_kats(jsg, oracle, golden):
+    for n, d in golden["kats"]["geometry_fs48000_mem10"].items():
+        for pct, (hop, fb, W) in d.items():
+            assert jsg.feed_samples(float(pct), int(n)) == hop
+            assert jsg.memsize_blocks(10.0, 48000.0, hop) == W
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        pct = float(rng.choice([100.0, 50.0, 25.0, 12.5, 10.0, 6.25]))
+        n = int(rng.choice([512, 1024, 2048, 4096, 8192]))
+        fs = float(rng.choice([44100.0, 48000.0, 96000.0, 192000.0]))
+        mem = float(rng.uniform(0.05, 20.0))
+        hop = jsg.feed_samples(pct, n)
+        assert hop == oracle.feed_samples(pct, n)
+        assert jsg.memsize_blocks(mem, fs, hop) == oracle.memsize_blocks(mem, fs, hop)
+    for ms in (1.0, 5.0, 10.0, 21.3, 42.0, 100.0):
+        assert jsg.next_power_of_2(ms, 48000.0) == oracle.next_power_of_2(ms, 48000.0)
+
+
+def test_colormap_tables_bit_exact_vs_reference_golden(jsg, golden):
+    g = golden["colormap"]
+    for scheme in range(7):
+        assert (jsg.colormap_lut(256, scheme) == np.array(g["lut256"][str(scheme)], dtype=np.int32)).all()
+        for n in (2, 7, 64, 100, 1000):
+            ref = np.array(g["lut_other"][f"{scheme}:{n}"], dtype=np.int32)
+            assert (jsg.colormap_lut(n, scheme) == ref).all(), (scheme, n)
+
+
+def test_colormap_range_bit_exact_vs_reference_golden(jsg, golden):
+    for case in golden["colormap"]["map_cases"]:
+        st = np.array(case["state_hex"], dtype=np.uint32)
+        got = np.array(jsg.colormap_range(case["n_colors"], case["lo"], case["hi"]), dtype=np.float32).view(np.uint32)
+        assert (got == st).all(), case["lo"]
+
+
+def test_ccolorpalette_mirror(jsg, golden):
+    p = jsg.CColorPalette(256, jsg.CColorPalette.kJade)
+    p.setValueRange(-50.0, 50.0)
+    assert abs(float(p.m_AccessMult) - golden["kats"]["colormap_range_m50_p50"]["access_mult"]) < 1e-7
+    p.setColorSceme(4)
+    assert (p.m_Color == np.array(golden["colormap"]["switch_scheme"]["6->4"], dtype=np.int32)).all()
+
+
+def test_bad_arguments_are_rejected(jsg):
+    lib = jsg.capi.lib()
+    assert lib.jsg_window_build(9, 1024, np.zeros(1024, np.float32).ctypes.data) == jsg.capi.JSG_ERR_INVALID
+    assert lib.jsg_colormap_build(256, 7, np.zeros(256, np.int32).ctypes.data) == jsg.capi.JSG_ERR_INVALID
+    assert lib.jsg_feed_samples(50.0, 0) == jsg.capi.JSG_ERR_INVALID
+
+
+def test_no_cpu_fallback(jsg):
+    """Without a GPU the engine must refuse loudly, not compute on the host."""
+    import pytest
+    if jsg.capi.lib().jsg_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(jsg.JsgError) as ei:
+        jsg.Spectrogram(2)
+    assert ei.value.code == jsg.capi.JSG_ERR_NO_DEVICE
+    with pytest.raises(jsg.JsgError):
+        jsg.Plan(1024, jsg.window(1, 1024))
