@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Headline benchmark: STFT frames/sec (1024-pt, 50 % hop) on N MI355X, with the kernel's HBM roofline fraction.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
+
+A "step" is one launch of the fused STFT->dB kernel over one batch of BASELINE.json configs[1]:
+mono 48 kHz, 1024-point FFT, hop 512, Hann, 4096 frames per launch, input stream and dB ring resident in HBM.
+Every rank works on its own independent streams (weak scaling, no data-path collective: the path shards by
+channel/stream); RCCL is used only for the barriers and the max-over-ranks time.
+
+To keep the numbers honest against the 256 MiB Infinity Cache, the steps rotate over NBUF distinct input/output
+batches (> 256 MiB in total), so every launch streams its 8.4 MB in and 8.4 MB out from/to HBM.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_FFT, HOP, FRAMES = 1024, 512, 4096
+H = N_FFT // 2 + 1
+ALGO_BYTES_PER_FRAME = 4 * HOP + 4 * H          # input counted once + one dB column = 4100 B
+HBM_PEAK_GBS = 8000.0                           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(seconds_budget: float = 12.0):
+    """The oracle's CPU path timed on this host (rank 0, N=1 only): reported baseline, not the target."""
+    import numpy as np
+    from oracle import jsg_oracle as oracle
+    try:
+        from oracle import oracle_c
+        port = oracle_c.load()
+    except Exception:
+        port = None
+    win = oracle.window(oracle.WIN_HANN, N_FFT)
+    if port is not None:
+        frames = 20000
+        x = oracle.synth_audio(1, frames * HOP + N_FFT)
+        t0 = time.perf_counter(); done = 0
+        while time.perf_counter() - t0 < seconds_budget:
+            port.stft_db(x, N_FFT, HOP, frames, win)
+            done += frames
+        dt = time.perf_counter() - t0
+        return {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                "sample": f"{done} frames of the bench workload through oracle/jsg_oracle_c.c (scalar float32 C port "
+                          f"of Spectrogram::processSynchronBlock, 1 thread) in {dt:.1f} s"}
+    frames = 8192
+    x = oracle.synth_audio(1, frames * HOP + N_FFT)
+    t0 = time.perf_counter(); done = 0
+    while time.perf_counter() - t0 < seconds_budget:
+        oracle.stft_db_reference(x[:, N_FFT:], N_FFT, HOP, 2, win)
+        done += (x.shape[1] - N_FFT) // N_FFT * 2
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{done} frames through oracle/jsg_oracle.py (numpy float64 rfft restatement) in {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--nbuf", type=int, default=24, help="distinct batches rotated through (24 x 16.8 MB > 256 MiB)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import jadespectrogram_amd as jsg
+    from oracle import jsg_oracle as oracle   # synthetic input generator + cpu_baseline leg only
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- workload: NBUF independent mono batches per rank, resident in HBM ----
+    win = jsg.window(jsg.capi.WIN_HANN, N_FFT)
+    plan = jsg.Plan(N_FFT, win)
+    n_samples = FRAMES * HOP + (N_FFT - HOP)
+    pitch = (H + 31) // 32 * 32
+    d_in, d_out = [], []
+    base = oracle.synth_audio(1, n_samples + args.nbuf * 64, seed=1234 + 1000 * rank)   # SURVEY 8d signal
+    for b in range(args.nbuf):
+        d_in.append(torch.from_numpy(np.ascontiguousarray(base[:, b * 64:b * 64 + n_samples])).cuda())
+        d_out.append(torch.empty((FRAMES, pitch), dtype=torch.float32, device="cuda"))
+    stream = torch.cuda.current_stream()
+
+    def step(i):
+        b = i % args.nbuf
+        jsg.stft_db(plan, d_in[b], HOP, FRAMES, d_out[b], feedblocks=2, stream=stream.cuda_stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for i in range(args.steps):
+        step(i)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier(); torch.cuda.synchronize()
+    wall = t1 - t0
+    ev_ms = ev0.elapsed_time(ev1)                       # events on the stream the kernel runs on
+    if dist is not None:
+        t = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, ev_ms = float(t[0]), float(t[1])
+
+    # parity spot check of what was just timed (rank 0): dB column of the last batch vs the oracle
+    if rank == 0:
+        b = (args.steps - 1) % args.nbuf
+        got = d_out[b][:4, :H].cpu().numpy()
+        ref = oracle.stft_db_reference(np.zeros((1, 0), np.float32), N_FFT, HOP, 2, win) if False else None
+        x = d_in[b][0, :N_FFT + 3 * HOP].cpu().numpy()
+        fr = np.stack([x[j * HOP:j * HOP + N_FFT] * win for j in range(4)]).astype(np.float32)
+        ref = oracle.to_db(oracle.power_spectrum(fr))
+        assert np.abs(got - ref).max() < 5e-3, "bench output drifted from the oracle"
+
+    frames_total = world * args.steps * FRAMES
+    kernel_s = ev_ms * 1e-3 / args.steps                # average launch-to-launch time of the kernel on its stream
+    achieved = ALGO_BYTES_PER_FRAME * FRAMES / kernel_s / 1e9
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if os.path.exists(prof):
+        try:
+            traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "STFT frames/sec (1024-pt, 50% hop)", "value": frames_total / wall, "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: mono 48 kHz, 1024-pt FFT, 512 hop, Hann, 4096 frames/launch, "
+                               "input+dB ring resident in HBM", "frames_per_launch": FRAMES, "channels_per_gpu": 1,
+                   "distinct_batches": args.nbuf, "parallelism": f"{world} independent streams (one per GPU)"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "stft_db_kernel<1024>", "avg_launch_us": kernel_s * 1e6,
+                     "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * FRAMES},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -113,6 +113,14 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  jadespectrogram_amd has no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64.  If libjsg.so is
+        # loaded first it pulls in /opt/rocm's copies, and the second runtime to initialise then sees no device.
+        # Importing torch first makes the dynamic loader resolve libjsg.so's libamdhip64.so.7 to the copy that is
+        # already mapped.  (A C++/JUCE host without torch simply uses /opt/rocm's runtime.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)   # AttributeError if the library does not export a declared symbol

@@ -25,7 +25,7 @@ def assert_power_close(p_gpu, p_ref64, what=""):
     err = np.abs(p_gpu - p_ref64)
     bad = err > tol
     assert not bad.any(), f"{what}: {bad.sum()} bins out of tolerance, worst ratio {np.max(err / tol):.3g}"
-    strong = p_ref64 > 1e-4 * peak
+    strong = p_ref64 > 1e-2 * peak   # bins within 20 dB of the frame peak: plain 1e-5 relative must hold
     return float(np.max(err[strong] / p_ref64[strong])) if strong.any() else 0.0
 
 
