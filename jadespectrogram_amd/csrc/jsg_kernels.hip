@@ -117,7 +117,9 @@ struct __attribute__((packed, aligned(4))) f2u {
 // ------------------------------------------------------------------------------------------------------------
 // per-size configuration (mirrors tools/fft_model.py CONFIGS; layouts found by its conflict search)
 // ------------------------------------------------------------------------------------------------------------
-template <int N_, int R1_, int R2_, int R3_, int L_, int S1_, int AX_, int AY_, int AZ_, int WPB_, bool REGT_>
+// TLOC: where the lane tables (window pairs, stage-1/2 twiddles, post-pass twiddles; [4][P][64] float2) live:
+//   0 = read from global memory (L1/L2) at every use, 1 = staged once per workgroup into LDS and read from there.
+template <int N_, int R1_, int R2_, int R3_, int L_, int S1_, int AX_, int AY_, int AZ_, int WPB_, int TLOC_, int WPS_>
 struct Cfg {
     static constexpr int N = N_, M = N_ / 2, R1 = R1_, R2 = R2_, R3 = R3_, L = L_;
     static constexpr int P = M / L;                  // complex values per lane
@@ -126,33 +128,38 @@ struct Cfg {
     static constexpr int SUB = 64 / L;               // frames per wavefront
     static constexpr int WPB = WPB_;                 // wavefronts per workgroup
     static constexpr int TPB = WPB * SUB;            // frames per workgroup per iteration
-    static constexpr bool REGT = REGT_;              // keep window + twiddle tables in registers
+    static constexpr int TLOC = TLOC_;
+    static constexpr int WPS = WPS_;                 // waves per SIMD the register allocator is asked to allow
+    static constexpr int TAB_ELEMS = 4 * P * 64;     // float2 elements of the four lane tables
     static constexpr int e1max = (R1 - 1) * S1 + M / R1;
     static constexpr int e2max = (R1 - 1) * AX + (R2 - 1) * AY + (R3 - 1) * AZ + 1;
     static constexpr int raw = e1max > e2max ? (e1max > M + 1 ? e1max : M + 1) : (e2max > M + 1 ? e2max : M + 1);
     static constexpr int LDS_ELEMS = (raw + 1) & ~1;  // float2 elements per frame slot, 16-byte multiple
-    static constexpr int LDS_BYTES = LDS_ELEMS * 8 * TPB;
+    static constexpr int LDS_BYTES = LDS_ELEMS * TPB * 8;                          // dynamic: exchange buffers
+    static constexpr int LDS_TOTAL = LDS_BYTES + (TLOC == 1 ? TAB_ELEMS : 2) * 8;  // + static: lane tables
     static_assert(R1 * R2 * R3 == M, "radices");
     static_assert(P % R1 == 0 && P % R2 == 0 && P % R3 == 0, "each lane owns whole butterflies");
+    static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget of one CU");
 };
 
-using Cfg512 = Cfg<512, 8, 8, 4, 32, 36, 4, 33, 1, 4, true>;
-using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 4, true>;
-using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, false>;
-using Cfg4096 = Cfg<4096, 8, 16, 16, 64, 272, 272, 17, 1, 4, false>;
-using Cfg8192 = Cfg<8192, 16, 16, 16, 64, 272, 272, 17, 1, 2, false>;
+using Cfg512 = Cfg<512, 8, 8, 4, 32, 36, 4, 33, 1, 8, 1, 2>;
+using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2>;
+using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 1, 1>;
+using Cfg4096 = Cfg<4096, 8, 16, 16, 64, 272, 272, 17, 1, 4, 0, 1>;
+using Cfg8192 = Cfg<8192, 16, 16, 16, 64, 272, 272, 17, 1, 2, 0, 1>;
 
 struct StftKArgs {
     const float* in;
     long long in_pitch;
-    int channels;
     int hop, feedblocks;
-    int mixop;           // 0 sum (AbsMean), 1 max, 2 min
-    int c_begin, c_end;  // channel range that is combined into one column
-    int per_channel;     // one column per (channel, frame)
+    int regular;         // hop * feedblocks == N: frame j starts at j*hop (no division in the kernel)
+    int c_begin, c_end;  // channel range that is combined into one column (mixed modes)
+    int per_channel;     // one column per (channel, frame): blockIdx.y is the channel
     int linear;          // store linear power instead of dB
-    float inv_div;       // AbsMean: the divisor (float(C)); others: 1
-    long long first_frame, n_frames, n_tasks;
+    float scale;         // AbsMean: 1/C (exact for power-of-two C); others: 1
+    float divisor;       // AbsMean: float(C)
+    int exact_div;       // C is not a power of two: divide (IEEE) instead of scaling
+    unsigned first_frame, n_frames;
     float* out;
     long long out_pitch, out_cpitch;
     int ring_w, ring_pos;
@@ -169,43 +176,75 @@ __device__ __forceinline__ float to_db(float p) {
     return __builtin_fmaf(l2, kHi, l2 * kLo);
 }
 
-template <class C>
-__global__ __launch_bounds__(C::WPB * 64) void stft_db_kernel(const StftKArgs a) {
+template <int MIXOP>
+__device__ __forceinline__ float mix_combine(float acc, float pw) {
+    if constexpr (MIXOP == 0) return acc + pw;                  // AbsMean / Sum: m_powerfinal += m_power[cc]  (:72)
+    else if constexpr (MIXOP == 1) return pw > acc ? pw : acc;  // Max (:81)
+    else return pw < acc ? pw : acc;                            // Min (:89)
+}
+
+// MIXOP: 0 sum (AbsMean, Left, Right, per-channel), 1 max, 2 min
+template <class C, int MIXOP>
+__global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const StftKArgs a) {
+    // Two distinct LDS objects on purpose: the (read-only) lane tables and the exchange buffers.  With one object
+    // the compiler must assume that a table read may alias an exchange store and serialises them.
+    __shared__ __attribute__((aligned(16))) float2 s_tab[C::TLOC == 1 ? C::TAB_ELEMS : 2];
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int L = C::L, P = C::P, M = C::M, R1 = C::R1, R2 = C::R2, R3 = C::R3;
     constexpr int U1 = C::U1, U2 = C::U2, U3 = C::U3;
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps task math scalar
     const int ll = lane % L;
     const int sub = lane / L;
-    float2* lds = reinterpret_cast<float2*>(smem_raw) + (wave * C::SUB + sub) * C::LDS_ELEMS;
+    float2* const lds = reinterpret_cast<float2*>(smem_raw) + (wave * C::SUB + sub) * C::LDS_ELEMS;
 
     // XCD-aware block remap (bijective): blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD one
     // contiguous range of frames so that the overlapped halves of neighbouring frames hit the same L2.
-    const int nblk = gridDim.x, b = blockIdx.x;
-    const int q = nblk >> 3, r = nblk & 7, xcd = b & 7;
-    const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const unsigned nblk = gridDim.x, b = blockIdx.x;
+    const unsigned q = nblk >> 3, r = nblk & 7, xcd = b & 7;
+    const unsigned lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 
-    // loop-invariant lane constants
-    const float2* tWin = a.tab + lane;
-    const float2* tTw1 = tWin + P * 64;
-    const float2* tTw2 = tTw1 + P * 64;
-    const float2* tPost = tTw2 + P * 64;
-    float2 rWin[C::REGT ? P : 1], rTw1[C::REGT ? P : 1], rTw2[C::REGT ? P : 1], rPost[C::REGT ? P : 1];
-    if constexpr (C::REGT) {
-#pragma unroll
-        for (int j = 0; j < P; ++j) {
-            rWin[j] = tWin[j * 64];
-            rTw1[j] = tTw1[j * 64];
-            rTw2[j] = tTw2[j * 64];
-            rPost[j] = tPost[j * 64];
+    // ---- task bookkeeping (32-bit, scalar): task t of this launch is frame t; the channel range is fixed ----
+    const unsigned task0 = lb * (unsigned)a.iters * C::TPB + wave * C::SUB;   // first task of this wave (sub 0)
+    const int c0 = a.per_channel ? (int)blockIdx.y : a.c_begin;
+    const int c1 = a.per_channel ? (int)blockIdx.y + 1 : a.c_end;
+    auto frame_src = [&](unsigned it, int c) -> const f2u* {
+        unsigned t = task0 + it * C::TPB + sub;
+        if (t >= a.n_frames) t = a.n_frames - 1;   // keep the lanes busy with a duplicate; its stores are masked
+        const unsigned j = a.first_frame + t;
+        long long start;
+        if (a.regular) {
+            start = (long long)j * a.hop;
+        } else {   // the reference's perc10: every fft-size block restarts at offset 0 (Spectrogram.cpp:50-55,216)
+            const unsigned blk = j / (unsigned)a.feedblocks;
+            start = (long long)blk * C::N + (long long)(j - blk * a.feedblocks) * a.hop;
         }
+        return reinterpret_cast<const f2u*>(a.in + (long long)c * a.in_pitch + start) + ll;
+    };
+
+    // ---- issue the first frame's loads before anything else: HBM latency overlaps the table staging ----
+    f2u rawx[P];
+    {
+        const f2u* src = frame_src(0, c0);
+#pragma unroll
+        for (int m = 0; m < P; ++m) rawx[m] = src[L * m];
     }
-#define JSG_WIN(j) (C::REGT ? rWin[C::REGT ? (j) : 0] : tWin[(j) * 64])
-#define JSG_TW1(j) (C::REGT ? rTw1[C::REGT ? (j) : 0] : tTw1[(j) * 64])
-#define JSG_TW2(j) (C::REGT ? rTw2[C::REGT ? (j) : 0] : tTw2[(j) * 64])
-#define JSG_POST(j) (C::REGT ? rPost[C::REGT ? (j) : 0] : tPost[(j) * 64])
+
+    // ---- lane tables: staged once per workgroup into LDS (16-byte coalesced), or left in global memory ----
+    const float2* tWin;
+    if constexpr (C::TLOC == 1) {
+        const float4* g4 = reinterpret_cast<const float4*>(a.tab);
+        float4* s4 = reinterpret_cast<float4*>(s_tab);
+        for (int i = threadIdx.x; i < C::TAB_ELEMS / 2; i += C::WPB * 64) s4[i] = g4[i];
+        __syncthreads();
+        tWin = s_tab + lane;
+    } else {
+        tWin = a.tab + lane;
+    }
+    const float2* const tTw1 = tWin + P * 64;
+    const float2* const tTw2 = tTw1 + P * 64;
+    const float2* const tPost = tTw2 + P * 64;
 
     // per-lane LDS element offsets of the two exchanges
     int e1r[U2], e2w[U2], e2r[U3];
@@ -222,40 +261,29 @@ __global__ __launch_bounds__(C::WPB * 64) void stft_db_kernel(const StftKArgs a)
     }
 
     for (int it = 0; it < a.iters; ++it) {
-        long long task = ((long long)lb * a.iters + it) * C::TPB + wave * C::SUB + sub;
-        const bool valid = task < a.n_tasks;
-        if (task >= a.n_tasks) task = a.n_tasks - 1;   // keep the lanes busy with a duplicate; stores are masked
-        long long jj;        // frame index inside this launch
-        int c0, c1;
-        if (a.per_channel) {
-            const int ch = (int)(task / a.n_frames);
-            jj = task - (long long)ch * a.n_frames;
-            c0 = ch;
-            c1 = ch + 1;
-        } else {
-            jj = task;
-            c0 = a.c_begin;
-            c1 = a.c_end;
-        }
-        const long long j = a.first_frame + jj;
-        const long long start = (j / a.feedblocks) * (long long)C::N + (j % a.feedblocks) * (long long)a.hop;
-
         float acc[P];
-        float accNy = 0.f;
-        const float init = (a.mixop == 2) ? 1000000.0f : 0.0f;   // reference Spectrogram.cpp:69,78,86
+        float accNy;
+        constexpr float init = (MIXOP == 2) ? 1000000.0f : 0.0f;   // reference Spectrogram.cpp:69,78,86
 #pragma unroll
         for (int m = 0; m < P; ++m) acc[m] = init;
         accNy = init;
 
         for (int c = c0; c < c1; ++c) {
-            // ---- load the frame (each lane: P pairs of consecutive samples) and apply the window ----
-            const f2u* src = reinterpret_cast<const f2u*>(a.in + (long long)c * a.in_pitch + start) + ll;
+            // ---- window multiply (the frame was loaded one FFT ago) ----
             float2 x[P];
 #pragma unroll
             for (int m = 0; m < P; ++m) {
-                const f2u s = src[L * m];
-                const float2 w = JSG_WIN(m);
-                x[m] = make_float2(s.x * w.x, s.y * w.y);
+                const float2 w = tWin[m * 64];
+                x[m] = make_float2(rawx[m].x * w.x, rawx[m].y * w.y);
+            }
+            // ---- software prefetch: issue the loads of the next FFT (next channel, or next task's first) ----
+            {
+                const bool more_c = c + 1 < c1;
+                if (more_c || it + 1 < a.iters) {
+                    const f2u* src = more_c ? frame_src(it, c + 1) : frame_src(it + 1, c0);
+#pragma unroll
+                    for (int m = 0; m < P; ++m) rawx[m] = src[L * m];
+                }
             }
             // ---- stage 1: radix-R1 over n1, twiddle W_{R1R2}^{n2 k1}, exchange 1 ----
 #pragma unroll
@@ -266,7 +294,7 @@ __global__ __launch_bounds__(C::WPB * 64) void stft_db_kernel(const StftKArgs a)
                 dft<R1>(t);
                 lds[ll + L * u] = t[0];
 #pragma unroll
-                for (int k1 = 1; k1 < R1; ++k1) lds[k1 * C::S1 + ll + L * u] = cmul(t[k1], JSG_TW1(u * R1 + k1));
+                for (int k1 = 1; k1 < R1; ++k1) lds[k1 * C::S1 + ll + L * u] = cmul(t[k1], tTw1[(u * R1 + k1) * 64]);
             }
             wave_sync();
             // ---- stage 2: radix-R2 over n2, twiddle W_M^{n3 (k1 + R1 k2)}, exchange 2 ----
@@ -283,7 +311,7 @@ __global__ __launch_bounds__(C::WPB * 64) void stft_db_kernel(const StftKArgs a)
                 for (int n2 = 0; n2 < R2; ++n2) t[n2] = x[v * R2 + n2];
                 dft<R2>(t);
 #pragma unroll
-                for (int k2 = 0; k2 < R2; ++k2) lds[e2w[v] + k2 * C::AY] = cmul(t[k2], JSG_TW2(v * R2 + k2));
+                for (int k2 = 0; k2 < R2; ++k2) lds[e2w[v] + k2 * C::AY] = cmul(t[k2], tTw2[(v * R2 + k2) * 64]);
             }
             wave_sync();
             // ---- stage 3: radix-R3 over n3; Z[k], k = t3 + R1 R2 k3 ----
@@ -293,7 +321,6 @@ __global__ __launch_bounds__(C::WPB * 64) void stft_db_kernel(const StftKArgs a)
                 for (int n3 = 0; n3 < R3; ++n3) x[w * R3 + n3] = lds[e2r[w] + n3 * C::AZ];
             }
             wave_sync();
-            float2 zp[P];
 #pragma unroll
             for (int w = 0; w < U3; ++w) {
                 float2 t[R3];
@@ -309,6 +336,7 @@ __global__ __launch_bounds__(C::WPB * 64) void stft_db_kernel(const StftKArgs a)
             if (ll == 0) lds[M] = x[0];   // Z[M] := Z[0]
             wave_sync();
             // ---- real-split post pass: X[k] = (Z[k] + conj Z[M-k])/2 - i/2 W_N^k (Z[k] - conj Z[M-k]) ----
+            float2 zp[P];
 #pragma unroll
             for (int w = 0; w < U3; ++w) {
 #pragma unroll
@@ -320,48 +348,38 @@ __global__ __launch_bounds__(C::WPB * 64) void stft_db_kernel(const StftKArgs a)
                 const float2 z = x[m], p = zp[m];
                 const float2 S = make_float2(z.x + p.x, z.y - p.y);
                 const float2 D = make_float2(z.x - p.x, z.y + p.y);
-                const float2 W = JSG_POST(m);
+                const float2 W = tPost[m * 64];
                 const float xr = 0.5f * S.x + (W.x * D.x - W.y * D.y);
                 const float xi = 0.5f * S.y + (W.x * D.y + W.y * D.x);
-                const float pw = xr * xr + xi * xi;
-                if (a.mixop == 0) acc[m] += pw;
-                else if (a.mixop == 1) acc[m] = pw > acc[m] ? pw : acc[m];
-                else acc[m] = pw < acc[m] ? pw : acc[m];
+                acc[m] = mix_combine<MIXOP>(acc[m], xr * xr + xi * xi);
             }
             {   // Nyquist bin X[M] = Re Z0 - Im Z0 (only lane 0 of the frame holds Z[0] in x[0])
                 const float d = x[0].x - x[0].y;
-                const float pw = d * d;
-                if (a.mixop == 0) accNy += pw;
-                else if (a.mixop == 1) accNy = pw > accNy ? pw : accNy;
-                else accNy = pw < accNy ? pw : accNy;
+                accNy = mix_combine<MIXOP>(accNy, d * d);
             }
         }
 
         // ---- mix epilogue + dB + ring store ----
-        const long long col = (a.ring_pos + jj) % a.ring_w;
-        float* dst = a.out + col * a.out_pitch + (a.per_channel ? (long long)c0 * a.out_cpitch : 0ll);
-        const bool divide = a.inv_div != 1.0f;
-        if (valid) {
+        const unsigned t = task0 + it * C::TPB + sub;
+        unsigned col = a.ring_pos + t;                     // n_frames <= ring_w (checked by the launcher)
+        if (col >= (unsigned)a.ring_w) col -= a.ring_w;
+        float* dst = a.out + (long long)col * a.out_pitch + (a.per_channel ? (long long)c0 * a.out_cpitch : 0ll);
+        if (t < a.n_frames) {
 #pragma unroll
             for (int w = 0; w < U3; ++w) {
 #pragma unroll
                 for (int k3 = 0; k3 < R3; ++k3) {
-                    float pw = acc[w * R3 + k3];
-                    if (divide) pw = pw / a.inv_div;     // m_powerfinal[kk] /= m_channels (IEEE divide)
+                    const float v = acc[w * R3 + k3];
+                    const float pw = a.exact_div ? v / a.divisor : v * a.scale;     // m_powerfinal[kk] /= m_channels
                     dst[ll + L * w + R1 * R2 * k3] = a.linear ? pw : to_db(pw);
                 }
             }
             if (ll == 0) {
-                float pw = accNy;
-                if (divide) pw = pw / a.inv_div;
+                const float pw = a.exact_div ? accNy / a.divisor : accNy * a.scale;
                 dst[M] = a.linear ? pw : to_db(pw);
             }
         }
     }
-#undef JSG_WIN
-#undef JSG_TW1
-#undef JSG_TW2
-#undef JSG_POST
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -478,24 +496,30 @@ static void fill_tables(std::vector<float2>& t, const float* window, double amp)
     }
 }
 
-template <class C>
-static hipError_t launch_stft(const StftKArgs& ka, int nblk, hipStream_t s) {
+template <class C, int MIXOP>
+static hipError_t launch_stft_mix(const StftKArgs& ka, dim3 grid, hipStream_t s) {
     static bool attr_done[64] = {};
     int dev = 0;
     hipError_t err = hipGetDevice(&dev);
     if (err != hipSuccess) return err;
     if (C::LDS_BYTES > 48 * 1024 && dev < 64 && !attr_done[dev]) {
-        err = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_db_kernel<C>),
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_db_kernel<C, MIXOP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (err != hipSuccess) return err;
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL(stft_db_kernel<C>, dim3(nblk), dim3(C::WPB * 64), C::LDS_BYTES, s, ka);
+    hipLaunchKernelGGL((stft_db_kernel<C, MIXOP>), grid, dim3(C::WPB * 64), C::LDS_BYTES, s, ka);
     return hipGetLastError();
 }
 
 template <class C>
-static int tasks_per_block() { return C::TPB; }
+static hipError_t launch_stft(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s) {
+    switch (mixop) {
+        case 1: return launch_stft_mix<C, 1>(ka, grid, s);
+        case 2: return launch_stft_mix<C, 2>(ka, grid, s);
+        default: return launch_stft_mix<C, 0>(ka, grid, s);
+    }
+}
 
 }  // namespace jsg
 
@@ -567,14 +591,18 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
         g->first_frame < 0 || g->ring_width <= 0 || g->ring_pos < 0 || g->ring_pos >= g->ring_width ||
         g->out_pitch < H)
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: bad geometry");
+    if (g->n_frames > g->ring_width)
+        return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: more frames than ring columns in one launch (columns would race)");
+    if (g->n_frames >= (1ll << 31) || g->first_frame + g->n_frames >= (1ll << 31))
+        return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_db_launch: frame index does not fit 31 bits");
     StftKArgs ka{};
     ka.in = g->in;
     ka.in_pitch = g->in_pitch;
-    ka.channels = g->channels;
     ka.hop = g->hop;
     ka.feedblocks = g->feedblocks;
-    ka.first_frame = g->first_frame;
-    ka.n_frames = g->n_frames;
+    ka.regular = ((long long)g->hop * g->feedblocks == plan->n) ? 1 : 0;
+    ka.first_frame = (unsigned)g->first_frame;
+    ka.n_frames = (unsigned)g->n_frames;
     ka.out = g->out_db;
     ka.out_pitch = g->out_pitch;
     ka.out_cpitch = g->out_channel_pitch;
@@ -584,12 +612,20 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
     ka.per_channel = 0;
     ka.c_begin = 0;
     ka.c_end = g->channels;
-    ka.inv_div = 1.0f;
-    ka.mixop = 0;
+    ka.scale = 1.0f;
+    ka.divisor = 1.0f;
+    ka.exact_div = 0;
+    int mixop = 0;
     switch (g->mix_mode) {
-        case JSG_MIX_ABSMEAN: ka.inv_div = float(g->channels); break;
-        case JSG_MIX_MAX: ka.mixop = 1; break;
-        case JSG_MIX_MIN: ka.mixop = 2; break;
+        case JSG_MIX_ABSMEAN:
+            // m_powerfinal[kk] /= m_channels (Spectrogram.cpp:74).  For a power-of-two channel count the division
+            // is an exact scaling and is done as one multiply; otherwise the kernel performs the IEEE division.
+            ka.divisor = float(g->channels);
+            ka.scale = 1.0f / float(g->channels);
+            ka.exact_div = (g->channels & (g->channels - 1)) != 0;
+            break;
+        case JSG_MIX_MAX: mixop = 1; break;
+        case JSG_MIX_MIN: mixop = 2; break;
         case JSG_MIX_LEFT: ka.c_end = 1; break;
         case JSG_MIX_RIGHT:
             // reference Spectrogram.cpp:97-105 reads m_power[1] whenever m_channels > 0; with one channel that is
@@ -603,7 +639,6 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
         default: return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: unknown mix mode");
     }
     ka.linear = g->linear_out ? 1 : 0;
-    ka.n_tasks = ka.per_channel ? g->n_frames * g->channels : g->n_frames;
     int tpb = 0;
     switch (plan->n) {
         case 512: tpb = Cfg512::TPB; break;
@@ -612,18 +647,22 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
         case 4096: tpb = Cfg4096::TPB; break;
         case 8192: tpb = Cfg8192::TPB; break;
     }
-    const long long want = (ka.n_tasks + tpb - 1) / tpb;
-    const long long max_blocks = 256ll * 16;   // a few resident workgroups per CU; the rest is looped over
+    const long long want = (g->n_frames + tpb - 1) / tpb;
+    const int ny = ka.per_channel ? g->channels : 1;
+    if (ny > 65535) return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_db_launch: more than 65535 channels in per-channel mode");
+    long long max_blocks = 256ll * 8 / ny;     // a few resident workgroups per CU; the rest is looped over
+    if (max_blocks < 64) max_blocks = 64;
     const int nblk = int(want < max_blocks ? want : max_blocks);
-    ka.iters = int((ka.n_tasks + (long long)nblk * tpb - 1) / ((long long)nblk * tpb));
+    ka.iters = int((g->n_frames + (long long)nblk * tpb - 1) / ((long long)nblk * tpb));
+    const dim3 grid(nblk, ny);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipError_t err = hipSuccess;
     switch (plan->n) {
-        case 512: err = launch_stft<Cfg512>(ka, nblk, s); break;
-        case 1024: err = launch_stft<Cfg1024>(ka, nblk, s); break;
-        case 2048: err = launch_stft<Cfg2048>(ka, nblk, s); break;
-        case 4096: err = launch_stft<Cfg4096>(ka, nblk, s); break;
-        case 8192: err = launch_stft<Cfg8192>(ka, nblk, s); break;
+        case 512: err = launch_stft<Cfg512>(ka, mixop, grid, s); break;
+        case 1024: err = launch_stft<Cfg1024>(ka, mixop, grid, s); break;
+        case 2048: err = launch_stft<Cfg2048>(ka, mixop, grid, s); break;
+        case 4096: err = launch_stft<Cfg4096>(ka, mixop, grid, s); break;
+        case 8192: err = launch_stft<Cfg8192>(ka, mixop, grid, s); break;
     }
     if (err != hipSuccess) return jsg_fail_hip(err, "jsg_stft_db_launch");
     return JSG_OK;
