@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <new>
 #include <utility>
 #include <vector>
@@ -118,9 +119,16 @@ struct __attribute__((packed, aligned(4))) f2u {
 // per-size configuration (mirrors tools/fft_model.py CONFIGS; layouts found by its conflict search)
 // ------------------------------------------------------------------------------------------------------------
 // TLOC: where the lane tables (window pairs, stage-1/2 twiddles, post-pass twiddles; [4][P][64] float2) live:
-//   0 = read from global memory (L1/L2) at every use, 1 = staged once per workgroup into LDS and read from there.
-template <int N_, int R1_, int R2_, int R3_, int L_, int S1_, int AX_, int AY_, int AZ_, int WPB_, int TLOC_, int WPS_>
+//   0 = read from global memory (L1/L2) at every use, 1 = staged once per workgroup into LDS and read from there,
+//   2 = loaded once per wave into registers.
+// XCH1: exchange 1 through LDS (0) or through lane swaps in registers (1, 8x8x8 plan only).
+// ZX  : partner fetch of the post pass through LDS (0) or ds_bpermute (1, 8x8x8 plan only).
+template <int N_, int R1_, int R2_, int R3_, int L_, int S1_, int AX_, int AY_, int AZ_, int WPB_, int TLOC_, int WPS_,
+          int XCH1_ = 0, int ZX_ = 0, int PF_ = 1, int ABL_ = 0>
 struct Cfg {
+    static constexpr int ABL = ABL_;                 // development ablations: 1 = memory traffic only, 2 = compute only
+    static constexpr int XCH1 = XCH1_, ZX = ZX_;
+    static constexpr int PF = PF_;                   // software-prefetch depth in FFTs (1 or 2)
     static constexpr int N = N_, M = N_ / 2, R1 = R1_, R2 = R2_, R3 = R3_, L = L_;
     static constexpr int P = M / L;                  // complex values per lane
     static constexpr int U1 = P / R1, U2 = P / R2, U3 = P / R3;
@@ -142,11 +150,21 @@ struct Cfg {
     static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget of one CU");
 };
 
-using Cfg512 = Cfg<512, 8, 8, 4, 32, 36, 4, 33, 1, 8, 1, 2>;
-using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2>;
+using Cfg512 = Cfg<512, 8, 8, 4, 32, 36, 4, 33, 1, 8, 1, 2, 0, 0, 1>;
+// default 1024-point plan: both exchanges through LDS, prefetch depth 1, 8 waves per workgroup (fastest of the
+// measured variants, DESIGN.md "Kernel variants")
+using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1>;
+// development variants of the 1024-point plan (selected with JSG_1024_VARIANT, see tools/sweep_variants.sh)
+using Cfg1024B = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 0, 2>;
+using Cfg1024C = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 2>;
+using Cfg1024D = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 1, 1>;
+using Cfg1024E = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 4, 1, 2, 0, 0, 1>;
+using Cfg1024F = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 16, 1, 4, 0, 0, 1>;
+using Cfg1024G = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 1>;
+using Cfg1024H = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 2>;
 using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 1, 1>;
-using Cfg4096 = Cfg<4096, 8, 16, 16, 64, 272, 272, 17, 1, 4, 0, 1>;
-using Cfg8192 = Cfg<8192, 16, 16, 16, 64, 272, 272, 17, 1, 2, 0, 1>;
+using Cfg4096 = Cfg<4096, 8, 16, 16, 64, 272, 272, 17, 1, 4, 0, 1, 0, 0, 0>;
+using Cfg8192 = Cfg<8192, 16, 16, 16, 64, 272, 272, 17, 1, 2, 0, 1, 0, 0, 0>;
 
 struct StftKArgs {
     const float* in;
@@ -183,6 +201,24 @@ __device__ __forceinline__ float mix_combine(float acc, float pw) {
     else return pw < acc ? pw : acc;                            // Min (:89)
 }
 
+// Cross-lane helpers for the register-only exchange (gfx950: v_permlane32_swap / v_permlane16_swap / DPP row_ror).
+__device__ __forceinline__ void swap_lane32(float& a, float& b) {   // a[lanes 32..63] <-> b[lanes 0..31]
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap_lane16(float& a, float& b) {   // a[odd 16-lane rows] <-> b[even rows]
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap_lane8(float& a, float& b, bool hi) {   // a[lane bit3 = 1] <-> b[lane bit3 = 0]
+    const float send = hi ? a : b;
+    const float recv = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(send), 0x128 /*row_ror:8*/, 0xf, 0xf, false));
+    a = hi ? recv : a;
+    b = hi ? b : recv;
+}
+
 // MIXOP: 0 sum (AbsMean, Left, Right, per-channel), 1 max, 2 min
 template <class C, int MIXOP>
 __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const StftKArgs a) {
@@ -209,7 +245,11 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const Stft
     const unsigned task0 = lb * (unsigned)a.iters * C::TPB + wave * C::SUB;   // first task of this wave (sub 0)
     const int c0 = a.per_channel ? (int)blockIdx.y : a.c_begin;
     const int c1 = a.per_channel ? (int)blockIdx.y + 1 : a.c_end;
-    auto frame_src = [&](unsigned it, int c) -> const f2u* {
+    const int nc = c1 - c0;
+    const int n_fft = a.iters * nc;   // FFTs this wave performs, s = it*nc + (c - c0)
+    auto frame_src = [&](int s) -> const f2u* {
+        const unsigned it = (nc == 1) ? (unsigned)s : (unsigned)s / (unsigned)nc;
+        const int c = c0 + (s - (int)it * nc);
         unsigned t = task0 + it * C::TPB + sub;
         if (t >= a.n_frames) t = a.n_frames - 1;   // keep the lanes busy with a duplicate; its stores are masked
         const unsigned j = a.first_frame + t;
@@ -223,15 +263,20 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const Stft
         return reinterpret_cast<const f2u*>(a.in + (long long)c * a.in_pitch + start) + ll;
     };
 
-    // ---- issue the first frame's loads before anything else: HBM latency overlaps the table staging ----
-    f2u rawx[P];
-    {
-        const f2u* src = frame_src(0, c0);
+    // ---- issue the loads of the first two FFTs before anything else (software pipeline, depth 2) ----
+    f2u rawA[P], rawB[C::PF == 2 ? P : 1];
+    if constexpr (C::PF > 0 && C::ABL != 2) {
+        const f2u* src = frame_src(0);
 #pragma unroll
-        for (int m = 0; m < P; ++m) rawx[m] = src[L * m];
+        for (int m = 0; m < P; ++m) rawA[m] = src[L * m];
+        if (C::PF == 2 && n_fft > 1) {
+            const f2u* src1 = frame_src(1);
+#pragma unroll
+            for (int m = 0; m < (C::PF == 2 ? P : 1); ++m) rawB[m] = src1[L * m];
+        }
     }
 
-    // ---- lane tables: staged once per workgroup into LDS (16-byte coalesced), or left in global memory ----
+    // ---- lane tables: registers (TLOC 2), LDS staged once per workgroup (TLOC 1), or global/L1 (TLOC 0) ----
     const float2* tWin;
     if constexpr (C::TLOC == 1) {
         const float4* g4 = reinterpret_cast<const float4*>(a.tab);
@@ -245,6 +290,18 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const Stft
     const float2* const tTw1 = tWin + P * 64;
     const float2* const tTw2 = tTw1 + P * 64;
     const float2* const tPost = tTw2 + P * 64;
+    constexpr int NR = C::TLOC == 2 ? P : 1;
+    float2 rWin[NR], rTw1[NR], rTw2[NR], rPost[NR];
+    if constexpr (C::TLOC == 2) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            rWin[j] = tWin[j * 64];
+            rTw1[j] = tTw1[j * 64];
+            rTw2[j] = tTw2[j * 64];
+            rPost[j] = tPost[j * 64];
+        }
+    }
+#define JSG_T(reg, ptr, j) (C::TLOC == 2 ? reg[C::TLOC == 2 ? (j) : 0] : ptr[(j) * 64])
 
     // per-lane LDS element offsets of the two exchanges
     int e1r[U2], e2w[U2], e2r[U3];
@@ -259,33 +316,77 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const Stft
         const int t3 = ll + L * w;
         e2r[w] = (t3 % R1) * C::AX + (t3 / R1) * C::AY;
     }
+    const bool lane_bit3 = (lane & 8) != 0;
+    const int zsrc = ((64 - lane) & 63) * 4;   // ds_bpermute address of the lane holding Z[M-k]
 
-    for (int it = 0; it < a.iters; ++it) {
-        float acc[P];
-        float accNy;
-        constexpr float init = (MIXOP == 2) ? 1000000.0f : 0.0f;   // reference Spectrogram.cpp:69,78,86
+    float acc[P];
+    float accNy;
+    constexpr float init = (MIXOP == 2) ? 1000000.0f : 0.0f;   // reference Spectrogram.cpp:69,78,86
 #pragma unroll
-        for (int m = 0; m < P; ++m) acc[m] = init;
-        accNy = init;
+    for (int m = 0; m < P; ++m) acc[m] = init;
+    accNy = init;
 
-        for (int c = c0; c < c1; ++c) {
-            // ---- window multiply (the frame was loaded one FFT ago) ----
-            float2 x[P];
+    // One FFT of the sequence: consumes `raw` (loaded two FFTs ago), re-issues it for FFT s+2, transforms,
+    // accumulates |X|^2 into acc, and after the last channel of a column runs the mix epilogue + ring store.
+    auto process = [&](auto& raw, int s) {
+        // ---- window multiply ----
+        float2 x[P];
+        if constexpr (C::ABL == 2) {
 #pragma unroll
-            for (int m = 0; m < P; ++m) {
-                const float2 w = tWin[m * 64];
-                x[m] = make_float2(rawx[m].x * w.x, rawx[m].y * w.y);
+            for (int m = 0; m < P; ++m) { raw[m].x = __int_as_float(0x3f800000 + lane + m + s); raw[m].y = 0.5f; }
+        }
+        if constexpr (C::PF == 0) {   // no software prefetch (large plans: registers are better spent on the data)
+            const f2u* src = frame_src(s);
+#pragma unroll
+            for (int m = 0; m < P; ++m) raw[m] = src[L * m];
+        }
+#pragma unroll
+        for (int m = 0; m < P; ++m) {
+            const float2 w = JSG_T(rWin, tWin, m);
+            x[m] = make_float2(raw[m].x * w.x, raw[m].y * w.y);
+        }
+        if (C::ABL != 2 && C::PF > 0 && s + C::PF < n_fft) {
+            const f2u* src = frame_src(s + C::PF);
+#pragma unroll
+            for (int m = 0; m < P; ++m) raw[m] = src[L * m];
+        }
+        if constexpr (C::ABL == 1) {   // ablation: memory traffic only (results are meaningless)
+#pragma unroll
+            for (int m = 0; m < P; ++m) acc[m] += x[m].x * x[m].y;
+            accNy += x[0].x;
+        }
+        if constexpr (C::ABL != 1) {
+        // ---- stage 1: radix-R1 over n1, twiddle W_{R1R2}^{n2 k1}, exchange 1 ----
+        if constexpr (C::XCH1 == 1) {
+            // register-only exchange: transpose lane bits 5:3 with the register index (lane (b,c) reg p ->
+            // lane (p,c) reg b) by three swap steps, no LDS traffic and no LDS round-trip latency
+            static_assert(C::XCH1 == 0 || (L == 64 && P == 8 && R1 == 8 && R2 == 8 && R3 == 8), "swap exchange is for the 8x8x8 plan");
+            float2 t[R1];
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) t[n1] = x[n1];
+            dft<R1>(t);
+#pragma unroll
+            for (int k1 = 1; k1 < R1; ++k1) t[k1] = cmul(t[k1], JSG_T(rTw1, tTw1, k1));
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                swap_lane32(t[p].x, t[p + 4].x);
+                swap_lane32(t[p].y, t[p + 4].y);
             }
-            // ---- software prefetch: issue the loads of the next FFT (next channel, or next task's first) ----
-            {
-                const bool more_c = c + 1 < c1;
-                if (more_c || it + 1 < a.iters) {
-                    const f2u* src = more_c ? frame_src(it, c + 1) : frame_src(it + 1, c0);
 #pragma unroll
-                    for (int m = 0; m < P; ++m) rawx[m] = src[L * m];
+            for (int p = 0; p < 8; ++p) {
+                if ((p & 2) == 0) {
+                    swap_lane16(t[p].x, t[p + 2].x);
+                    swap_lane16(t[p].y, t[p + 2].y);
                 }
             }
-            // ---- stage 1: radix-R1 over n1, twiddle W_{R1R2}^{n2 k1}, exchange 1 ----
+#pragma unroll
+            for (int p = 0; p < 8; p += 2) {
+                swap_lane8(t[p].x, t[p + 1].x, lane_bit3);
+                swap_lane8(t[p].y, t[p + 1].y, lane_bit3);
+            }
+#pragma unroll
+            for (int n2 = 0; n2 < R2; ++n2) x[n2] = t[n2];
+        } else {
 #pragma unroll
             for (int u = 0; u < U1; ++u) {
                 float2 t[R1];
@@ -294,92 +395,131 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const Stft
                 dft<R1>(t);
                 lds[ll + L * u] = t[0];
 #pragma unroll
-                for (int k1 = 1; k1 < R1; ++k1) lds[k1 * C::S1 + ll + L * u] = cmul(t[k1], tTw1[(u * R1 + k1) * 64]);
+                for (int k1 = 1; k1 < R1; ++k1) lds[k1 * C::S1 + ll + L * u] = cmul(t[k1], JSG_T(rTw1, tTw1, u * R1 + k1));
             }
             wave_sync();
-            // ---- stage 2: radix-R2 over n2, twiddle W_M^{n3 (k1 + R1 k2)}, exchange 2 ----
 #pragma unroll
             for (int v = 0; v < U2; ++v) {
 #pragma unroll
                 for (int n2 = 0; n2 < R2; ++n2) x[v * R2 + n2] = lds[e1r[v] + n2 * R3];
             }
             wave_sync();
+        }
+        // ---- stage 2: radix-R2 over n2, twiddle W_M^{n3 (k1 + R1 k2)}, exchange 2 ----
 #pragma unroll
-            for (int v = 0; v < U2; ++v) {
-                float2 t[R2];
+        for (int v = 0; v < U2; ++v) {
+            float2 t[R2];
 #pragma unroll
-                for (int n2 = 0; n2 < R2; ++n2) t[n2] = x[v * R2 + n2];
-                dft<R2>(t);
+            for (int n2 = 0; n2 < R2; ++n2) t[n2] = x[v * R2 + n2];
+            dft<R2>(t);
 #pragma unroll
-                for (int k2 = 0; k2 < R2; ++k2) lds[e2w[v] + k2 * C::AY] = cmul(t[k2], tTw2[(v * R2 + k2) * 64]);
+            for (int k2 = 0; k2 < R2; ++k2) lds[e2w[v] + k2 * C::AY] = cmul(t[k2], JSG_T(rTw2, tTw2, v * R2 + k2));
+        }
+        wave_sync();
+        // ---- stage 3: radix-R3 over n3; Z[k], k = t3 + R1 R2 k3 ----
+#pragma unroll
+        for (int w = 0; w < U3; ++w) {
+#pragma unroll
+            for (int n3 = 0; n3 < R3; ++n3) x[w * R3 + n3] = lds[e2r[w] + n3 * C::AZ];
+        }
+        wave_sync();
+        float2 zp[P];
+#pragma unroll
+        for (int w = 0; w < U3; ++w) {
+            float2 t[R3];
+#pragma unroll
+            for (int n3 = 0; n3 < R3; ++n3) t[n3] = x[w * R3 + n3];
+            dft<R3>(t);
+#pragma unroll
+            for (int k3 = 0; k3 < R3; ++k3) x[w * R3 + k3] = t[k3];
+        }
+        // ---- partner fetch Z[M-k] for the real-split post pass ----
+        if constexpr (C::ZX == 1) {
+            // k = lane + 64 k3  ->  M-k = (64-lane) + 64 (7-k3): register 7-k3 of lane 64-lane; lane 0 pairs with
+            // itself: Z[64 (8-k3)], i.e. its own register (8-k3) mod 8 (Z[M] = Z[0])
+            static_assert(C::ZX == 0 || (L == 64 && P == 8 && U3 == 1), "bpermute partner fetch is for the 8x8x8 plan");
+#pragma unroll
+            for (int k3 = 0; k3 < 8; ++k3) {
+                const float2 own = (lane == 0) ? x[(8 - k3) & 7] : x[7 - k3];
+                zp[k3].x = __uint_as_float(__builtin_amdgcn_ds_bpermute(zsrc, __float_as_uint(own.x)));
+                zp[k3].y = __uint_as_float(__builtin_amdgcn_ds_bpermute(zsrc, __float_as_uint(own.y)));
             }
-            wave_sync();
-            // ---- stage 3: radix-R3 over n3; Z[k], k = t3 + R1 R2 k3 ----
+        } else {
 #pragma unroll
             for (int w = 0; w < U3; ++w) {
 #pragma unroll
-                for (int n3 = 0; n3 < R3; ++n3) x[w * R3 + n3] = lds[e2r[w] + n3 * C::AZ];
-            }
-            wave_sync();
-#pragma unroll
-            for (int w = 0; w < U3; ++w) {
-                float2 t[R3];
-#pragma unroll
-                for (int n3 = 0; n3 < R3; ++n3) t[n3] = x[w * R3 + n3];
-                dft<R3>(t);
-#pragma unroll
-                for (int k3 = 0; k3 < R3; ++k3) {
-                    x[w * R3 + k3] = t[k3];
-                    lds[ll + L * w + R1 * R2 * k3] = t[k3];
-                }
+                for (int k3 = 0; k3 < R3; ++k3) lds[ll + L * w + R1 * R2 * k3] = x[w * R3 + k3];
             }
             if (ll == 0) lds[M] = x[0];   // Z[M] := Z[0]
             wave_sync();
-            // ---- real-split post pass: X[k] = (Z[k] + conj Z[M-k])/2 - i/2 W_N^k (Z[k] - conj Z[M-k]) ----
-            float2 zp[P];
 #pragma unroll
             for (int w = 0; w < U3; ++w) {
 #pragma unroll
                 for (int k3 = 0; k3 < R3; ++k3) zp[w * R3 + k3] = lds[M - (ll + L * w + R1 * R2 * k3)];
             }
-            wave_sync();   // the next FFT's exchange-1 stores must stay behind these loads
-#pragma unroll
-            for (int m = 0; m < P; ++m) {
-                const float2 z = x[m], p = zp[m];
-                const float2 S = make_float2(z.x + p.x, z.y - p.y);
-                const float2 D = make_float2(z.x - p.x, z.y + p.y);
-                const float2 W = tPost[m * 64];
-                const float xr = 0.5f * S.x + (W.x * D.x - W.y * D.y);
-                const float xi = 0.5f * S.y + (W.x * D.y + W.y * D.x);
-                acc[m] = mix_combine<MIXOP>(acc[m], xr * xr + xi * xi);
-            }
-            {   // Nyquist bin X[M] = Re Z0 - Im Z0 (only lane 0 of the frame holds Z[0] in x[0])
-                const float d = x[0].x - x[0].y;
-                accNy = mix_combine<MIXOP>(accNy, d * d);
-            }
+            wave_sync();   // the next FFT's exchange stores must stay behind these loads
         }
+        // ---- real-split post pass: X[k] = (Z[k] + conj Z[M-k])/2 - i/2 W_N^k (Z[k] - conj Z[M-k]) ----
+#pragma unroll
+        for (int m = 0; m < P; ++m) {
+            const float2 z = x[m], p = zp[m];
+            const float2 S = make_float2(z.x + p.x, z.y - p.y);
+            const float2 D = make_float2(z.x - p.x, z.y + p.y);
+            const float2 W = JSG_T(rPost, tPost, m);
+            const float xr = 0.5f * S.x + (W.x * D.x - W.y * D.y);
+            const float xi = 0.5f * S.y + (W.x * D.y + W.y * D.x);
+            acc[m] = mix_combine<MIXOP>(acc[m], xr * xr + xi * xi);
+        }
+        {   // Nyquist bin X[M] = Re Z0 - Im Z0 (only lane 0 of the frame holds Z[0] in x[0])
+            const float d = x[0].x - x[0].y;
+            accNy = mix_combine<MIXOP>(accNy, d * d);
+        }
+        }   // ABL != 1
 
-        // ---- mix epilogue + dB + ring store ----
-        const unsigned t = task0 + it * C::TPB + sub;
-        unsigned col = a.ring_pos + t;                     // n_frames <= ring_w (checked by the launcher)
-        if (col >= (unsigned)a.ring_w) col -= a.ring_w;
-        float* dst = a.out + (long long)col * a.out_pitch + (a.per_channel ? (long long)c0 * a.out_cpitch : 0ll);
-        if (t < a.n_frames) {
+        // ---- last channel of this column: mix epilogue + dB + ring store ----
+        const unsigned it = (nc == 1) ? (unsigned)s : (unsigned)s / (unsigned)nc;
+        if (s - (int)it * nc == nc - 1) {
+            const unsigned t = task0 + it * C::TPB + sub;
+            unsigned col = a.ring_pos + t;                     // n_frames <= ring_w (checked by the launcher)
+            if (col >= (unsigned)a.ring_w) col -= a.ring_w;
+            float* dst = a.out + (long long)col * a.out_pitch + (a.per_channel ? (long long)c0 * a.out_cpitch : 0ll);
+            if (a.exact_div) {   // m_powerfinal[kk] /= m_channels (Spectrogram.cpp:74), IEEE division
 #pragma unroll
-            for (int w = 0; w < U3; ++w) {
+                for (int m = 0; m < P; ++m) acc[m] = acc[m] / a.divisor;
+                accNy = accNy / a.divisor;
+            } else {             // power-of-two channel count: the same division as an exact scaling
 #pragma unroll
-                for (int k3 = 0; k3 < R3; ++k3) {
-                    const float v = acc[w * R3 + k3];
-                    const float pw = a.exact_div ? v / a.divisor : v * a.scale;     // m_powerfinal[kk] /= m_channels
-                    dst[ll + L * w + R1 * R2 * k3] = a.linear ? pw : to_db(pw);
+                for (int m = 0; m < P; ++m) acc[m] *= a.scale;
+                accNy *= a.scale;
+            }
+            if (!a.linear) {
+#pragma unroll
+                for (int m = 0; m < P; ++m) acc[m] = to_db(acc[m]);
+                accNy = to_db(accNy);
+            }
+            if (C::ABL == 2 ? (acc[0] == 12345.678f) : (t < a.n_frames)) {
+#pragma unroll
+                for (int w = 0; w < U3; ++w) {
+#pragma unroll
+                    for (int k3 = 0; k3 < R3; ++k3) dst[ll + L * w + R1 * R2 * k3] = acc[w * R3 + k3];
                 }
+                if (ll == 0) dst[M] = accNy;
             }
-            if (ll == 0) {
-                const float pw = a.exact_div ? accNy / a.divisor : accNy * a.scale;
-                dst[M] = a.linear ? pw : to_db(pw);
-            }
+#pragma unroll
+            for (int m = 0; m < P; ++m) acc[m] = init;
+            accNy = init;
         }
+    };
+
+    if constexpr (C::PF == 2) {
+        for (int s = 0; s < n_fft; s += 2) {
+            process(rawA, s);
+            if (s + 1 < n_fft) process(rawB, s + 1);
+        }
+    } else {
+        for (int s = 0; s < n_fft; ++s) process(rawA, s);
     }
+#undef JSG_T
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -642,7 +782,11 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
     int tpb = 0;
     switch (plan->n) {
         case 512: tpb = Cfg512::TPB; break;
-        case 1024: tpb = Cfg1024::TPB; break;
+        case 1024: {
+            const char* e = getenv("JSG_1024_VARIANT");
+            tpb = (e && e[0] == 'E') ? Cfg1024E::TPB : (e && e[0] == 'F') ? Cfg1024F::TPB : Cfg1024::TPB;
+            break;
+        }
         case 2048: tpb = Cfg2048::TPB; break;
         case 4096: tpb = Cfg4096::TPB; break;
         case 8192: tpb = Cfg8192::TPB; break;
@@ -650,7 +794,12 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
     const long long want = (g->n_frames + tpb - 1) / tpb;
     const int ny = ka.per_channel ? g->channels : 1;
     if (ny > 65535) return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_db_launch: more than 65535 channels in per-channel mode");
-    long long max_blocks = 256ll * 8 / ny;     // a few resident workgroups per CU; the rest is looped over
+    static const int blocks_per_cu = [] {   // tuning knob (development): JSG_STFT_BLOCKS_PER_CU
+        const char* e = getenv("JSG_STFT_BLOCKS_PER_CU");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 8;
+    }();
+    long long max_blocks = 256ll * blocks_per_cu / ny;     // resident workgroups; the rest is looped over
     if (max_blocks < 64) max_blocks = 64;
     const int nblk = int(want < max_blocks ? want : max_blocks);
     ka.iters = int((g->n_frames + (long long)nblk * tpb - 1) / ((long long)nblk * tpb));
@@ -659,7 +808,20 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
     hipError_t err = hipSuccess;
     switch (plan->n) {
         case 512: err = launch_stft<Cfg512>(ka, mixop, grid, s); break;
-        case 1024: err = launch_stft<Cfg1024>(ka, mixop, grid, s); break;
+        case 1024: {
+            static const int variant = [] { const char* e = getenv("JSG_1024_VARIANT"); return e ? e[0] : '-'; }();
+            switch (variant) {
+                case 'B': err = launch_stft<Cfg1024B>(ka, mixop, grid, s); break;
+                case 'C': err = launch_stft<Cfg1024C>(ka, mixop, grid, s); break;
+                case 'D': err = launch_stft<Cfg1024D>(ka, mixop, grid, s); break;
+                case 'E': err = launch_stft<Cfg1024E>(ka, mixop, grid, s); break;
+                case 'F': err = launch_stft<Cfg1024F>(ka, mixop, grid, s); break;
+                case 'G': err = launch_stft<Cfg1024G>(ka, mixop, grid, s); break;
+                case 'H': err = launch_stft<Cfg1024H>(ka, mixop, grid, s); break;
+                default: err = launch_stft<Cfg1024>(ka, mixop, grid, s); break;
+            }
+            break;
+        }
         case 2048: err = launch_stft<Cfg2048>(ka, mixop, grid, s); break;
         case 4096: err = launch_stft<Cfg4096>(ka, mixop, grid, s); break;
         case 8192: err = launch_stft<Cfg8192>(ka, mixop, grid, s); break;

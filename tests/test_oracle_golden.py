@@ -154,3 +154,19 @@ def test_display_oracle_recompute_matches_closed_form(oracle):
         nv, pos = d.timer_callback()
         assert nv == 2
         assert (d.img == oracle.render_all(s.mem, pos, d.palette, running=True)).all()
+
+
+def test_c_port_agrees_with_numpy_oracle(oracle):
+    """oracle/jsg_oracle_c.c (float32 scalar port, the cpu_baseline leg) against the float64 numpy restatement."""
+    from oracle import oracle_c
+    port = oracle_c.load()
+    for n, hop, fb, C, mix in ((1024, 512, 2, 1, 0), (2048, 512, 4, 3, 0), (1024, 102, 10, 2, 1), (512, 256, 2, 2, 4)):
+        K = 4
+        x = oracle.synth_audio(C, K * n, seed=4, kind="noise")
+        win = oracle.window(oracle.WIN_HANN, n)
+        xp = np.concatenate([np.zeros((C, n), np.float32), x], axis=1)
+        got = port.stft_db(xp, n, hop, K * fb, win, feedblocks=fb, mix=mix)
+        ref = oracle.stft_db_reference(x, n, hop, fb, win, mode=mix)
+        assert got.shape == ref.shape
+        assert (got[0] == np.float32(-110.0)).all()
+        assert np.abs(got - ref).max() < 2e-3 and np.median(np.abs(got - ref)) < 1e-5
