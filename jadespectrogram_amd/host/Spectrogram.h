@@ -1,0 +1,134 @@
+// Drop-in replacement for the engine half of the reference's `class Spectrogram` (reference Spectrogram.h:81-169,
+// Spectrogram.cpp:16-331).  Same public method names, argument meaning, return values and enumerator order; the
+// body is a thin veneer over the C-ABI of libjsg.so, i.e. all signal processing runs in hand-written HIP kernels
+// on an MI355X.  Header-only: add this directory to the include path and link libjsg.so.
+//
+//   PluginProcessor.cpp:102-114   prepareToPlay: preparetoProcess / setSamplerate / setmemoryTime_s / setFFTSize /
+//                                 setfeed_percent            -> unchanged call sites
+//   PluginProcessor.cpp:148       m_spectrogram.processBlock(buffer, midi)   -> unchanged
+//   Spectrogram.cpp:592-608       getMemorySize / getSpectrumSize / getMem   -> unchanged
+//   Spectrogram.cpp:623-724       the colour loops -> SpectrogramGpuDisplay::update (one call instead of the loops)
+//
+// Differences from the reference that a maintainer should know:
+//   * the channel count comes from preparetoProcess()/setchannels(); the reference keeps its ctor default of 2
+//     unless the (external) base class sets it;
+//   * there is no CPU fallback: if no MI355X is usable the constructor throws std::runtime_error;
+//   * getMem synchronises with the GPU stream; processSynchronBlock only enqueues work.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/jsg.h"
+#include "CColorpalette.h"
+#include "SynchronBlockProcessor.h"
+
+class Spectrogram : public SynchronBlockProcessor {
+public:
+    enum class ChannelMixMode { AbsMean, Max, Min, Left, Right };
+    enum class Windows { Rect, Hann, Hamming, BlackmanHarris, FlatTop, HannPoisson };
+    enum class FeedPercentage { perc100, perc50, perc25, perc10 };
+
+    Spectrogram() : SynchronBlockProcessor() {
+        jsg_engine* e = nullptr;
+        const int rc = jsg_create(&e, 2);   // m_channels(2), Spectrogram.cpp:17
+        if (rc != JSG_OK) throw std::runtime_error(std::string("Spectrogram: ") + jsg_last_error(nullptr));
+        m_engine.reset(e);
+        setDesiredBlockSizeSamples(size_t(jsg_get_fft_size(e)));
+    }
+
+    virtual int processSynchronBlock(std::vector<std::vector<float>>& data, juce::MidiBuffer& midiMessages) override {
+        juce::ignoreUnused(midiMessages);
+        const size_t ch = size_t(jsg_get_channels(m_engine.get()));
+        const size_t n = size_t(jsg_get_fft_size(m_engine.get()));
+        if (data.size() < ch) return JSG_ERR_SIZE_MISMATCH;
+        m_ptrs.resize(ch);
+        for (size_t c = 0; c < ch; ++c) {
+            if (data[c].size() < n) return JSG_ERR_SIZE_MISMATCH;
+            m_ptrs[c] = data[c].data();
+        }
+        return jsg_process_block(m_engine.get(), m_ptrs.data());
+    }
+    // void prepareParameter(std::unique_ptr<AudioProcessorValueTreeState>&) -- display parameters are GUI plumbing
+    // (reference Spectrogram.cpp:25-35) and stay in the plugin; nothing on the GPU depends on them.
+
+    // setter
+    void setSamplerate(float samplerate) { check(jsg_set_samplerate(m_engine.get(), samplerate)); }
+    void setchannels(size_t newchannels) { check(jsg_set_channels(m_engine.get(), int(newchannels))); }
+    void setFFTSize(size_t newFFTSize) {
+        check(jsg_set_fft_size(m_engine.get(), int(newFFTSize)));
+        setDesiredBlockSizeSamples(newFFTSize);
+    }
+    void setclosestFFTSize_ms(float fftsize_ms) { setFFTSize(getnextpowerof2(fftsize_ms)); }
+    void setmemoryTime_s(float memsize_s) { check(jsg_set_memory_time_s(m_engine.get(), memsize_s)); }
+    void setfeed_percent(FeedPercentage feed) { check(jsg_set_feed_percent(m_engine.get(), int(feed))); }
+    void setPauseMode(bool mode) { check(jsg_set_pause_mode(m_engine.get(), mode ? 1 : 0)); }
+    void setWindow(Spectrogram::Windows win) { check(jsg_set_window(m_engine.get(), int(win))); }
+
+    size_t getnextpowerof2(float fftsize_ms) {
+        return size_t(jsg_next_power_of_2(fftsize_ms, jsg_get_samplerate(m_engine.get())));
+    }
+
+    int getSpectrumSize() { return jsg_get_spectrum_size(m_engine.get()); }
+    int getMemorySize() { return jsg_get_memory_size(m_engine.get()); }
+    int getMem(std::vector<std::vector<float>>& mem, int& pos) {
+        const int W = getMemorySize(), H = getSpectrumSize();
+        if (int(mem.size()) != W) return -1;   // Spectrogram.cpp:297-298
+        // getMem copies only the new columns; keep the caller's other columns by staging through a dense mirror
+        if (m_dense.size() != size_t(W) * size_t(H)) m_dense.assign(size_t(W) * size_t(H), 0.f);
+        for (int c = 0; c < W; ++c)
+            if (int(mem[size_t(c)].size()) == H) std::copy(mem[size_t(c)].begin(), mem[size_t(c)].end(), m_dense.begin() + long(c) * H);
+        const int newVals = jsg_get_mem(m_engine.get(), m_dense.data(), W, &pos);
+        if (newVals < 0) return newVals;
+        for (int c = 0; c < W; ++c) {
+            if (int(mem[size_t(c)].size()) != H) continue;
+            std::copy(m_dense.begin() + long(c) * H, m_dense.begin() + long(c + 1) * H, mem[size_t(c)].begin());
+        }
+        return newVals;
+    }
+    float getSamplerate() { return jsg_get_samplerate(m_engine.get()); }
+
+    // extensions (not in the reference)
+    void setMixMode(ChannelMixMode m) { check(jsg_set_mix_mode(m_engine.get(), int(m))); }
+    void setPowerScale(float s) { check(jsg_set_power_scale(m_engine.get(), s)); }
+    jsg_engine* engine() { return m_engine.get(); }
+
+protected:
+    void channelsPrepared(size_t channels) override {
+        if (m_engine && int(channels) != jsg_get_channels(m_engine.get())) setchannels(channels);
+    }
+
+private:
+    struct Deleter {
+        void operator()(jsg_engine* e) const { jsg_destroy(e); }
+    };
+    void check(int rc) {
+        if (rc < 0) throw std::runtime_error(std::string("Spectrogram: ") + jsg_last_error(m_engine.get()));
+    }
+    std::unique_ptr<jsg_engine, Deleter> m_engine;
+    std::vector<const float*> m_ptrs;
+    std::vector<float> m_dense;
+};
+
+// The colour half of SpectrogramComponent::timerCallback (reference Spectrogram.cpp:590-731) as one call:
+//     gpuDisplay.update(minColorSlider, maxColorSlider, destData.data, destData.lineStride/4, newVals, pos);
+// replaces getMem + the pixel loops; the image is [getSpectrumSize()][getMemorySize()] 32-bit ARGB
+// (juce::Colour(uint32) order), low frequencies at the bottom, time running left to right.
+class SpectrogramGpuDisplay {
+public:
+    explicit SpectrogramGpuDisplay(Spectrogram& s, int nrOfColors = 256, int scheme = CColorPalette::kJade) : m_spec(s) {
+        setColorSceme(scheme, nrOfColors);   // m_colorpalette(256,6), reference Spectrogram.cpp:337
+    }
+    void setColorSceme(int scheme, int nrOfColors = 256) { jsg_display_set_colormap(m_spec.engine(), nrOfColors, scheme); }
+    void setRunningDisplay(bool running) { jsg_display_set_running(m_spec.engine(), running ? 1 : 0); }
+    void recomputeAll() { jsg_display_invalidate(m_spec.engine()); }
+    int update(float minColor, float maxColor, uint32_t* argb, int64_t pitchPixels, int& newVals, int& pos) {
+        return jsg_display_update(m_spec.engine(), minColor, maxColor, argb, pitchPixels, &newVals, &pos);
+    }
+
+private:
+    Spectrogram& m_spec;
+};

@@ -1,0 +1,149 @@
+"""BASELINE.json's full-size configurations: size-independent properties (Parseval, batching invariance, silence),
+plus spot checks of randomly chosen frames against the oracle."""
+import numpy as np
+import pytest
+
+from parity_util import assert_db_close, assert_power_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    return torch
+
+
+def _stream(torch, channels, n_samples, seed):
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    t = torch.arange(n_samples, device="cuda", dtype=torch.float64)
+    rows = []
+    for c in range(channels):
+        fc = 220.0 * 2.0 ** (c / 12.0)
+        u = torch.rand(n_samples, device="cuda", generator=g, dtype=torch.float64) * 2 - 1
+        rows.append((0.5 * torch.sin(2 * np.pi * fc * t / 48000.0) + 0.1 * u).to(torch.float32))
+    return torch.stack(rows).contiguous()
+
+
+def _parseval_check(torch, d_in, d_pow, n, hop, win, frames, mean_over_channels=True):
+    """sum_k c_k P[k] == N * sum_n (w x)^2  (c_k = 1 for k = 0, N/2, else 2), per column; AbsMean: channel mean."""
+    C = d_in.shape[0]
+    w = torch.from_numpy(win).cuda().to(torch.float64)
+    idx = (torch.tensor(frames, device="cuda")[:, None] * hop + torch.arange(n, device="cuda")[None, :])
+    fr = d_in[:, idx].to(torch.float32) * w.to(torch.float32)[None, None, :]
+    energy = (fr.to(torch.float64) ** 2).sum(-1) * n                      # [C][F]
+    if mean_over_channels:
+        energy = energy.mean(0)
+    P = d_pow[frames][:, :n // 2 + 1].to(torch.float64)
+    lhs = 2.0 * P.sum(-1) - P[:, 0] - P[:, n // 2]
+    rel = ((lhs - energy).abs() / energy).max().item()
+    assert rel < 2e-6, rel
+
+
+def _spot_check(oracle, d_in, got_db, n, hop, win, frames, mix=0):
+    x = d_in.cpu().numpy()
+    fr = np.stack([x[:, f * hop:f * hop + n] for f in frames], axis=1)    # [C][F][n]
+    fr = (fr * win[None, None, :]).astype(np.float32)
+    pw = oracle.power_spectrum_f64(fr)
+    mixed = oracle.mix_channels(pw.astype(np.float32), mix)
+    assert_db_close(got_db, oracle.to_db(mixed), mixed.astype(np.float64), "spot check")
+
+
+def test_c2_mono_1024_4096_frames_per_launch(jsg, oracle, torch_cuda):
+    torch = torch_cuda
+    n, hop, F = 1024, 512, 4096
+    win = oracle.window(oracle.WIN_HANN, n)
+    plan = jsg.Plan(n, win)
+    d_in = _stream(torch, 1, F * hop + n - hop, seed=1)
+    H, pitch = n // 2 + 1, 544
+    d_db = torch.empty((F, pitch), device="cuda")
+    d_pw = torch.empty((F, pitch), device="cuda")
+    jsg.stft_db(plan, d_in, hop, F, d_db)
+    jsg.stft_db(plan, d_in, hop, F, d_pw, linear_out=True)
+    # batching invariance: two launches of 2048 frames == one launch of 4096, bit for bit
+    d_two = torch.empty((F, pitch), device="cuda")
+    jsg.stft_db(plan, d_in, hop, 2048, d_two)
+    jsg.stft_db(plan, d_in, hop, 2048, d_two, first_frame=2048, ring_pos=2048)
+    torch.cuda.synchronize()
+    assert torch.equal(d_db[:, :H], d_two[:, :H])
+    frames = sorted(np.random.default_rng(0).choice(F, 64, replace=False).tolist())
+    _parseval_check(torch, d_in, d_pw, n, hop, win, frames)
+    _spot_check(oracle, d_in, d_db[frames][:, :H].cpu().numpy(), n, hop, win, frames)
+    # dB is the log of the linear output
+    ref = oracle.to_db(d_pw[:, :H].cpu().numpy())
+    assert np.abs(ref - d_db[:, :H].cpu().numpy()).max() < 3e-5
+    # silence -> exactly 10*log10(1e-11f)
+    jsg.stft_db(plan, torch.zeros_like(d_in), hop, F, d_db)
+    torch.cuda.synchronize()
+    assert bool((d_db[:, :H] == -110.0).all())
+
+
+def test_c3_8ch_2048_75pct_overlap(jsg, oracle, torch_cuda):
+    torch = torch_cuda
+    n, hop, F, C = 2048, 512, 2048, 8
+    win = oracle.window(oracle.WIN_HANN, n)
+    plan = jsg.Plan(n, win)
+    d_in = _stream(torch, C, F * hop + n - hop, seed=2)
+    H, pitch = n // 2 + 1, 1056
+    d_db = torch.empty((F, pitch), device="cuda")
+    d_pw = torch.empty((F, pitch), device="cuda")
+    jsg.stft_db(plan, d_in, hop, F, d_db, feedblocks=4)
+    jsg.stft_db(plan, d_in, hop, F, d_pw, feedblocks=4, linear_out=True)
+    torch.cuda.synchronize()
+    frames = sorted(np.random.default_rng(1).choice(F, 24, replace=False).tolist())
+    _parseval_check(torch, d_in, d_pw, n, hop, win, frames)
+    _spot_check(oracle, d_in, d_db[frames][:, :H].cpu().numpy(), n, hop, win, frames)
+
+
+def test_c4_shard_8ch_per_gpu_per_channel(jsg, oracle, torch_cuda):
+    """One GPU's share of the 64-channel configuration: 8 independent channels, no mix, through the sharded driver."""
+    torch = torch_cuda
+    from jadespectrogram_amd.sharded import GpuBackend, ShardedSpectrogram
+    n, hop, F, C = 1024, 512, 4096, 8
+    win = oracle.window(oracle.WIN_HANN, n)
+    d_in = _stream(torch, C, F * hop + n - hop, seed=3)
+    be = GpuBackend(n, hop, win)
+    be.to_device = lambda t: t                     # the stream is already resident
+    sh = ShardedSpectrogram(C, be)
+    assert list(sh.local_channels()) == list(range(8))
+    per = sh.per_channel(d_in, F)                  # [C][F][pitch]
+    mixed = sh.absmean(d_in, F)
+    torch.cuda.synchronize()
+    H = n // 2 + 1
+    frames = sorted(np.random.default_rng(2).choice(F, 16, replace=False).tolist())
+    for c in (0, 3, 7):
+        _spot_check(oracle, d_in[c:c + 1], per[c][frames][:, :H].cpu().numpy(), n, hop, win, frames)
+    _spot_check(oracle, d_in, mixed[frames][:, :H].cpu().numpy(), n, hop, win, frames)
+    # the sharded AbsMean (sum kernel + finish kernel) equals the fused AbsMean kernel bit for bit on one GPU
+    d_db = torch.empty((F, be.pitch), device="cuda")
+    jsg.stft_db(be.plan, d_in, hop, F, d_db)
+    torch.cuda.synchronize()
+    assert torch.equal(d_db[:, :H], mixed[:, :H])
+
+
+def test_c5_stereo_96k_4096_with_colormap(jsg, oracle, torch_cuda):
+    torch = torch_cuda
+    n, hop, F, C = 4096, 512, 1875, 2           # 87.5 % overlap, 10 s of 96 kHz -> W = 1875 columns
+    assert oracle.memsize_blocks(10.0, 96000.0, hop) == F
+    win = oracle.window(oracle.WIN_HANN, n)
+    plan = jsg.Plan(n, win)
+    d_in = _stream(torch, C, F * hop + n - hop, seed=4)
+    H, pitch = n // 2 + 1, 2080
+    d_db = torch.empty((F, pitch), device="cuda")
+    jsg.stft_db(plan, d_in, hop, F, d_db, feedblocks=8)
+    d_lut = torch.from_numpy(jsg.colormap_lut(256, jsg.capi.CM_JADE)).cuda()
+    d_img = torch.zeros((H, F), dtype=torch.int32, device="cuda")
+    d_idx = torch.zeros((H, F), dtype=torch.uint8, device="cuda")
+    pos = 700
+    jsg.colormap(d_db, d_lut, -50.0, 50.0, d_argb=d_img, d_index=d_idx, x_first=(F - pos) % F, height=H)
+    torch.cuda.synchronize()
+    frames = sorted(np.random.default_rng(3).choice(F, 8, replace=False).tolist())
+    _spot_check(oracle, d_in, d_db[frames][:, :H].cpu().numpy(), n, hop, win, frames)
+    db = d_db[:, :H].cpu().numpy()
+    pal = oracle.OracleColorPalette(256, oracle.CM_JADE); pal.set_value_range(-50.0, 50.0)
+    assert (d_img.cpu().numpy().view(np.uint32) == oracle.render_all(db, pos, pal, running=True)).all()
+    xs = (np.arange(F) + (F - pos)) % F
+    ref_idx = np.zeros((H, F), np.uint8); ref_idx[::-1, :][:, xs] = pal.index(db).T.astype(np.uint8)
+    assert (d_idx.cpu().numpy() == ref_idx).all()
