@@ -124,8 +124,9 @@ struct __attribute__((packed, aligned(4))) f2u {
 // XCH1: exchange 1 through LDS (0) or through lane swaps in registers (1, 8x8x8 plan only).
 // ZX  : partner fetch of the post pass through LDS (0) or ds_bpermute (1, 8x8x8 plan only).
 template <int N_, int R1_, int R2_, int R3_, int L_, int S1_, int AX_, int AY_, int AZ_, int WPB_, int TLOC_, int WPS_,
-          int XCH1_ = 0, int ZX_ = 0, int PF_ = 1, int ABL_ = 0>
+          int XCH1_ = 0, int ZX_ = 0, int PF_ = 1, int ABL_ = 0, bool NT_ = true>
 struct Cfg {
+    static constexpr bool NT = NT_;                  // non-temporal (streaming) stores of the dB columns
     static constexpr int ABL = ABL_;                 // development ablations: 1 = memory traffic only, 2 = compute only
     static constexpr int XCH1 = XCH1_, ZX = ZX_;
     static constexpr int PF = PF_;                   // software-prefetch depth in FFTs (1 or 2)
@@ -162,6 +163,9 @@ using Cfg1024E = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 4, 1, 2, 0, 0, 1>;
 using Cfg1024F = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 16, 1, 4, 0, 0, 1>;
 using Cfg1024G = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 1>;
 using Cfg1024H = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 2>;
+using Cfg1024S = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 3>;
+using Cfg1024N = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 0, false>;
+using Cfg1024M = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 1, true>;
 using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 1, 1>;
 using Cfg4096 = Cfg<4096, 8, 16, 16, 64, 272, 272, 17, 1, 4, 0, 1, 0, 0, 0>;
 using Cfg8192 = Cfg<8192, 16, 16, 16, 64, 272, 272, 17, 1, 2, 0, 1, 0, 0, 0>;
@@ -183,6 +187,7 @@ struct StftKArgs {
     int ring_w, ring_pos;
     int iters;
     const float2* tab;   // [4][P][64]: window pairs, stage-1 twiddles, stage-2 twiddles, post-pass twiddles
+    unsigned long long* stamps;   // development (ABL == 3): 4 s_memtime stamps per wave
 };
 
 // dB = 10*log10(p + 1e-11f) -- reference Spectrogram.cpp:107 with g_minValForLogSpectrogram (:36).
@@ -234,6 +239,9 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const Stft
     const int ll = lane % L;
     const int sub = lane / L;
     float2* const lds = reinterpret_cast<float2*>(smem_raw) + (wave * C::SUB + sub) * C::LDS_ELEMS;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    unsigned long long rt0 = 0;
+    if constexpr (C::ABL == 3) { st0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 
     // XCD-aware block remap (bijective): blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD one
     // contiguous range of frames so that the overlapped halves of neighbouring frames hit the same L2.
@@ -263,7 +271,19 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const Stft
         return reinterpret_cast<const f2u*>(a.in + (long long)c * a.in_pitch + start) + ll;
     };
 
-    // ---- issue the loads of the first two FFTs before anything else (software pipeline, depth 2) ----
+    // ---- lane tables first (L2-resident, 32 bytes per lane): their loads return before the frame's, so the
+    //      LDS staging and the workgroup barrier finish while the frame loads are still in flight ----
+    constexpr int NTL = C::TLOC == 1 ? (C::TAB_ELEMS / 2) / (C::WPB * 64) : 1;   // 16-byte table loads per thread
+    static_assert(C::TLOC != 1 || (C::TAB_ELEMS / 2) % (C::WPB * 64) == 0, "table size must divide evenly over the workgroup");
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f tabv[NTL];
+    if constexpr (C::TLOC == 1) {
+        const v4f* g4 = reinterpret_cast<const v4f*>(a.tab) + threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) tabv[i] = g4[i * C::WPB * 64];
+        __builtin_amdgcn_sched_barrier(0);   // keep the table loads OLDER than the frame loads (in-order vmcnt)
+    }
+    // ---- issue the loads of the first FFT(s) (software pipeline) ----
     f2u rawA[P], rawB[C::PF == 2 ? P : 1];
     if constexpr (C::PF > 0 && C::ABL != 2) {
         const f2u* src = frame_src(0);
@@ -274,14 +294,13 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const Stft
 #pragma unroll
             for (int m = 0; m < (C::PF == 2 ? P : 1); ++m) rawB[m] = src1[L * m];
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
-
-    // ---- lane tables: registers (TLOC 2), LDS staged once per workgroup (TLOC 1), or global/L1 (TLOC 0) ----
     const float2* tWin;
     if constexpr (C::TLOC == 1) {
-        const float4* g4 = reinterpret_cast<const float4*>(a.tab);
-        float4* s4 = reinterpret_cast<float4*>(s_tab);
-        for (int i = threadIdx.x; i < C::TAB_ELEMS / 2; i += C::WPB * 64) s4[i] = g4[i];
+        v4f* s4 = reinterpret_cast<v4f*>(s_tab) + threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) s4[i * C::WPB * 64] = tabv[i];
         __syncthreads();
         tWin = s_tab + lane;
     } else {
@@ -344,6 +363,10 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const Stft
         for (int m = 0; m < P; ++m) {
             const float2 w = JSG_T(rWin, tWin, m);
             x[m] = make_float2(raw[m].x * w.x, raw[m].y * w.y);
+        }
+        if constexpr (C::ABL == 3) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (s == 0) st1 = __builtin_readcyclecounter();
         }
         if (C::ABL != 2 && C::PF > 0 && s + C::PF < n_fft) {
             const f2u* src = frame_src(s + C::PF);
@@ -483,6 +506,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const Stft
             unsigned col = a.ring_pos + t;                     // n_frames <= ring_w (checked by the launcher)
             if (col >= (unsigned)a.ring_w) col -= a.ring_w;
             float* dst = a.out + (long long)col * a.out_pitch + (a.per_channel ? (long long)c0 * a.out_cpitch : 0ll);
+            if constexpr (C::ABL == 3) { if (s == 0) st2 = __builtin_readcyclecounter(); }
             if (a.exact_div) {   // m_powerfinal[kk] /= m_channels (Spectrogram.cpp:74), IEEE division
 #pragma unroll
                 for (int m = 0; m < P; ++m) acc[m] = acc[m] / a.divisor;
@@ -501,9 +525,15 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const Stft
 #pragma unroll
                 for (int w = 0; w < U3; ++w) {
 #pragma unroll
-                    for (int k3 = 0; k3 < R3; ++k3) dst[ll + L * w + R1 * R2 * k3] = acc[w * R3 + k3];
+                    for (int k3 = 0; k3 < R3; ++k3) {
+                        if constexpr (C::NT) __builtin_nontemporal_store(acc[w * R3 + k3], &dst[ll + L * w + R1 * R2 * k3]);
+                        else dst[ll + L * w + R1 * R2 * k3] = acc[w * R3 + k3];
+                    }
                 }
-                if (ll == 0) dst[M] = accNy;
+                if (ll == 0) {
+                    if constexpr (C::NT) __builtin_nontemporal_store(accNy, &dst[M]);
+                    else dst[M] = accNy;
+                }
             }
 #pragma unroll
             for (int m = 0; m < P; ++m) acc[m] = init;
@@ -518,6 +548,14 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const Stft
         }
     } else {
         for (int s = 0; s < n_fft; ++s) process(rawA, s);
+    }
+    if constexpr (C::ABL == 3) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st3 = __builtin_readcyclecounter();
+        if (lane == 0 && a.stamps) {
+            unsigned long long* d = a.stamps + (size_t)(blockIdx.x * C::WPB + wave) * 6;
+            d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3; d[4] = rt0; d[5] = __builtin_amdgcn_s_memrealtime();
+        }
     }
 #undef JSG_T
 }
@@ -672,7 +710,12 @@ struct jsg_plan {
     size_t tab_elems = 0;
 };
 
+static unsigned long long* g_dev_stamps = nullptr;
+
 extern "C" {
+
+// development only (not part of include/jsg.h): device buffer for the s_memtime stamps of variant 'S'
+void jsg_dev_set_stamp_buffer(void* p) { g_dev_stamps = static_cast<unsigned long long*>(p); }
 
 int jsg_device_count(void) {
     int n = 0;
@@ -749,6 +792,7 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
     ka.ring_w = g->ring_width;
     ka.ring_pos = g->ring_pos;
     ka.tab = plan->d_tab;
+    ka.stamps = g_dev_stamps;
     ka.per_channel = 0;
     ka.c_begin = 0;
     ka.c_end = g->channels;
@@ -818,6 +862,9 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
                 case 'F': err = launch_stft<Cfg1024F>(ka, mixop, grid, s); break;
                 case 'G': err = launch_stft<Cfg1024G>(ka, mixop, grid, s); break;
                 case 'H': err = launch_stft<Cfg1024H>(ka, mixop, grid, s); break;
+                case 'S': err = launch_stft<Cfg1024S>(ka, mixop, grid, s); break;
+                case 'N': err = launch_stft<Cfg1024N>(ka, mixop, grid, s); break;
+                case 'M': err = launch_stft<Cfg1024M>(ka, mixop, grid, s); break;
                 default: err = launch_stft<Cfg1024>(ka, mixop, grid, s); break;
             }
             break;
