@@ -121,6 +121,7 @@ def main():
     barrier(); torch.cuda.synchronize()
     wall = t1 - t0
     ev_ms = ev0.elapsed_time(ev1)                       # events on the stream the kernel runs on
+
     if dist is not None:
         t = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -130,20 +131,24 @@ def main():
     if rank == 0:
         b = (args.steps - 1) % args.nbuf
         got = d_out[b][:4, :H].cpu().numpy()
-        ref = oracle.stft_db_reference(np.zeros((1, 0), np.float32), N_FFT, HOP, 2, win) if False else None
         x = d_in[b][0, :N_FFT + 3 * HOP].cpu().numpy()
         fr = np.stack([x[j * HOP:j * HOP + N_FFT] * win for j in range(4)]).astype(np.float32)
         ref = oracle.to_db(oracle.power_spectrum(fr))
         assert np.abs(got - ref).max() < 5e-3, "bench output drifted from the oracle"
 
     frames_total = world * args.steps * FRAMES
-    kernel_s = ev_ms * 1e-3 / args.steps                # average launch-to-launch time of the kernel on its stream
+    # HIP events over the timed region, on the stream the kernel is launched on: average time per launch while the
+    # kernel streams back to back (consecutive dispatches overlap by ~1 us: the next one ramps up while the previous
+    # drains; rocprofv3's per-dispatch duration, profiles/r01_kernel_stats.csv, therefore reads ~1.2 us longer)
+    kernel_s = ev_ms * 1e-3 / args.steps
     achieved = ALGO_BYTES_PER_FRAME * FRAMES / kernel_s / 1e9
-    traffic = None
+    traffic, rocprof_us = None, None
     prof = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
     if os.path.exists(prof):
         try:
-            traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+            pj = json.load(open(prof))
+            traffic = pj.get("hbm_bytes_per_launch")            # PMC FETCH_SIZE x2 (gfx950) + WRITE_SIZE, per launch
+            rocprof_us = pj.get("avg_ns", 0.0) / 1e3 or None    # rocprofv3 --kernel-trace --stats of this command
         except Exception:
             traffic = None
     out = {
@@ -156,6 +161,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "stft_db_kernel<1024>", "avg_launch_us": kernel_s * 1e6,
+                     "rocprof_isolated_dispatch_us": rocprof_us,
                      "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * FRAMES},
     }
     if rank == 0:
