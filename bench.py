@@ -136,6 +136,25 @@ def main():
         ref = oracle.to_db(oracle.power_spectrum(fr))
         assert np.abs(got - ref).max() < 5e-3, "bench output drifted from the oracle"
 
+    # context for the roofline: a plain device-to-device copy of the SAME byte count (8.4 MB in, 8.4 MB out per launch),
+    # rotating over the same number of distinct buffers -- what this launch size can reach at all on this GPU
+    copy_us = None
+    if rank == 0:
+        nflt = ALGO_BYTES_PER_FRAME * FRAMES // 8
+        csrc = [torch.rand(nflt, device="cuda") for _ in range(args.nbuf)]
+        cdst = [torch.empty(nflt, device="cuda") for _ in range(args.nbuf)]
+        for i in range(50):
+            cdst[i % args.nbuf].copy_(csrc[i % args.nbuf])
+        torch.cuda.synchronize()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record(stream)
+        for i in range(500):
+            cdst[i % args.nbuf].copy_(csrc[i % args.nbuf])
+        c1.record(stream)
+        torch.cuda.synchronize()
+        copy_us = c0.elapsed_time(c1) * 1e3 / 500
+        del csrc, cdst
+
     frames_total = world * args.steps * FRAMES
     # HIP events over the timed region, on the stream the kernel is launched on: average time per launch while the
     # kernel streams back to back (consecutive dispatches overlap by ~1 us: the next one ramps up while the previous
@@ -162,6 +181,8 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "stft_db_kernel<1024>", "avg_launch_us": kernel_s * 1e6,
                      "rocprof_isolated_dispatch_us": rocprof_us,
+                     "memcpy_same_bytes_us": copy_us,
+                     "frac_of_memcpy_rate": (copy_us / (kernel_s * 1e6)) if copy_us else None,
                      "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * FRAMES},
     }
     if rank == 0:

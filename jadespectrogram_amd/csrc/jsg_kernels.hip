@@ -124,8 +124,11 @@ struct __attribute__((packed, aligned(4))) f2u {
 // XCH1: exchange 1 through LDS (0) or through lane swaps in registers (1, 8x8x8 plan only).
 // ZX  : partner fetch of the post pass through LDS (0) or ds_bpermute (1, 8x8x8 plan only).
 template <int N_, int R1_, int R2_, int R3_, int L_, int S1_, int AX_, int AY_, int AZ_, int WPB_, int TLOC_, int WPS_,
-          int XCH1_ = 0, int ZX_ = 0, int PF_ = 1, int ABL_ = 0, bool NT_ = true>
+          int XCH1_ = 0, int ZX_ = 0, int PF_ = 1, int ABL_ = 0, bool NT_ = true, bool PAIR_ = true>
 struct Cfg {
+    // PAIR: post pass computes X[k] and X[M-k] together from one (S, D, W*D) butterfly: each lane handles the pairs of
+    // its lower P/2 registers and stores both bins (8 fewer VALU ops per pair, half the partner fetches).
+    static constexpr bool PAIR = PAIR_ && ZX_ == 0;
     static constexpr bool NT = NT_;                  // non-temporal (streaming) stores of the dB columns
     static constexpr int ABL = ABL_;                 // development ablations: 1 = memory traffic only, 2 = compute only
     static constexpr int XCH1 = XCH1_, ZX = ZX_;
@@ -134,12 +137,14 @@ struct Cfg {
     static constexpr int P = M / L;                  // complex values per lane
     static constexpr int U1 = P / R1, U2 = P / R2, U3 = P / R3;
     static constexpr int S1 = S1_, AX = AX_, AY = AY_, AZ = AZ_;
-    static constexpr int SUB = 64 / L;               // frames per wavefront
+    static constexpr int SUB = L < 64 ? 64 / L : 1;  // frames per wavefront (L = 32: two)
+    static constexpr int WPF = L > 64 ? L / 64 : 1;  // wavefronts per frame (L = 128, 256: the exchanges use s_barrier)
+    static constexpr int TL = L > 64 ? L : 64;       // entries per lane-table row
     static constexpr int WPB = WPB_;                 // wavefronts per workgroup
-    static constexpr int TPB = WPB * SUB;            // frames per workgroup per iteration
+    static constexpr int TPB = WPB * 64 / L;         // frames per workgroup per iteration
     static constexpr int TLOC = TLOC_;
     static constexpr int WPS = WPS_;                 // waves per SIMD the register allocator is asked to allow
-    static constexpr int TAB_ELEMS = 4 * P * 64;     // float2 elements of the four lane tables
+    static constexpr int TAB_ELEMS = 4 * P * TL;     // float2 elements of the four lane tables
     static constexpr int e1max = (R1 - 1) * S1 + M / R1;
     static constexpr int e2max = (R1 - 1) * AX + (R2 - 1) * AY + (R3 - 1) * AZ + 1;
     static constexpr int raw = e1max > e2max ? (e1max > M + 1 ? e1max : M + 1) : (e2max > M + 1 ? e2max : M + 1);
@@ -148,6 +153,7 @@ struct Cfg {
     static constexpr int LDS_TOTAL = LDS_BYTES + (TLOC == 1 ? TAB_ELEMS : 2) * 8;  // + static: lane tables
     static_assert(R1 * R2 * R3 == M, "radices");
     static_assert(P % R1 == 0 && P % R2 == 0 && P % R3 == 0, "each lane owns whole butterflies");
+    static_assert(WPB % WPF == 0, "a workgroup holds whole frames");
     static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget of one CU");
 };
 
@@ -165,10 +171,11 @@ using Cfg1024G = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 1>;
 using Cfg1024H = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 2>;
 using Cfg1024S = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 3>;
 using Cfg1024N = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 0, false>;
+using Cfg1024U = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 0, true, false>;
 using Cfg1024M = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 1, true>;
 using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 1, 1>;
-using Cfg4096 = Cfg<4096, 8, 16, 16, 64, 272, 272, 17, 1, 4, 0, 1, 0, 0, 0>;
-using Cfg8192 = Cfg<8192, 16, 16, 16, 64, 272, 272, 17, 1, 2, 0, 1, 0, 0, 0>;
+using Cfg4096 = Cfg<4096, 16, 8, 16, 128, 144, 1, 272, 17, 8, 1, 1, 0, 0, 1>;    // two wavefronts per frame
+using Cfg8192 = Cfg<8192, 16, 16, 16, 256, 272, 1, 272, 17, 8, 0, 1, 0, 0, 1>;   // four wavefronts per frame
 
 struct StftKArgs {
     const float* in;
@@ -236,9 +243,13 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const Stft
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps task math scalar
-    const int ll = lane % L;
-    const int sub = lane / L;
-    float2* const lds = reinterpret_cast<float2*>(smem_raw) + (wave * C::SUB + sub) * C::LDS_ELEMS;
+    // frame slot inside the workgroup and lane index inside the frame (L lanes cooperate on one frame)
+    const int ll = L <= 64 ? lane % L : (wave % C::WPF) * 64 + lane;
+    const int sub = L <= 64 ? lane / L : 0;
+    const int slot0 = L <= 64 ? wave * C::SUB : wave / C::WPF;   // wave-uniform part of the slot
+    float2* const lds = reinterpret_cast<float2*>(smem_raw) + (slot0 + sub) * C::LDS_ELEMS;
+    constexpr int TL = C::TL;
+    const int tl = L <= 64 ? lane : ll;                           // index into a lane-table row
     unsigned long long st0 = 0, st1 = 0, st2 = 0;
     unsigned long long rt0 = 0;
     if constexpr (C::ABL == 3) { st0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const Stft
     const unsigned lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 
     // ---- task bookkeeping (32-bit, scalar): task t of this launch is frame t; the channel range is fixed ----
-    const unsigned task0 = lb * (unsigned)a.iters * C::TPB + wave * C::SUB;   // first task of this wave (sub 0)
+    const unsigned task0 = lb * (unsigned)a.iters * C::TPB + slot0;   // first task of this wave (sub 0)
     const int c0 = a.per_channel ? (int)blockIdx.y : a.c_begin;
     const int c1 = a.per_channel ? (int)blockIdx.y + 1 : a.c_end;
     const int nc = c1 - c0;
@@ -302,25 +313,31 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const Stft
 #pragma unroll
         for (int i = 0; i < NTL; ++i) s4[i * C::WPB * 64] = tabv[i];
         __syncthreads();
-        tWin = s_tab + lane;
+        tWin = s_tab + tl;
     } else {
-        tWin = a.tab + lane;
+        tWin = a.tab + tl;
     }
-    const float2* const tTw1 = tWin + P * 64;
-    const float2* const tTw2 = tTw1 + P * 64;
-    const float2* const tPost = tTw2 + P * 64;
+    const float2* const tTw1 = tWin + P * TL;
+    const float2* const tTw2 = tTw1 + P * TL;
+    const float2* const tPost = tTw2 + P * TL;
     constexpr int NR = C::TLOC == 2 ? P : 1;
     float2 rWin[NR], rTw1[NR], rTw2[NR], rPost[NR];
     if constexpr (C::TLOC == 2) {
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-            rWin[j] = tWin[j * 64];
-            rTw1[j] = tTw1[j * 64];
-            rTw2[j] = tTw2[j * 64];
-            rPost[j] = tPost[j * 64];
+            rWin[j] = tWin[j * TL];
+            rTw1[j] = tTw1[j * TL];
+            rTw2[j] = tTw2[j * TL];
+            rPost[j] = tPost[j * TL];
         }
     }
-#define JSG_T(reg, ptr, j) (C::TLOC == 2 ? reg[C::TLOC == 2 ? (j) : 0] : ptr[(j) * 64])
+#define JSG_T(reg, ptr, j) (C::TLOC == 2 ? reg[C::TLOC == 2 ? (j) : 0] : ptr[(j) * TL])
+    // exchange synchronisation: lock-step lanes of one wave need only a compiler fence; frames that span several
+    // waves (L > 64) need the workgroup barrier (every wave of the workgroup runs the same number of them)
+    auto frame_sync = [&]() {
+        if constexpr (L > 64) __syncthreads();
+        else wave_sync();
+    };
 
     // per-lane LDS element offsets of the two exchanges
     int e1r[U2], e2w[U2], e2r[U3];
@@ -420,13 +437,13 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const Stft
 #pragma unroll
                 for (int k1 = 1; k1 < R1; ++k1) lds[k1 * C::S1 + ll + L * u] = cmul(t[k1], JSG_T(rTw1, tTw1, u * R1 + k1));
             }
-            wave_sync();
+            frame_sync();
 #pragma unroll
             for (int v = 0; v < U2; ++v) {
 #pragma unroll
                 for (int n2 = 0; n2 < R2; ++n2) x[v * R2 + n2] = lds[e1r[v] + n2 * R3];
             }
-            wave_sync();
+            frame_sync();
         }
         // ---- stage 2: radix-R2 over n2, twiddle W_M^{n3 (k1 + R1 k2)}, exchange 2 ----
 #pragma unroll
@@ -438,14 +455,14 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const Stft
 #pragma unroll
             for (int k2 = 0; k2 < R2; ++k2) lds[e2w[v] + k2 * C::AY] = cmul(t[k2], JSG_T(rTw2, tTw2, v * R2 + k2));
         }
-        wave_sync();
+        frame_sync();
         // ---- stage 3: radix-R3 over n3; Z[k], k = t3 + R1 R2 k3 ----
 #pragma unroll
         for (int w = 0; w < U3; ++w) {
 #pragma unroll
             for (int n3 = 0; n3 < R3; ++n3) x[w * R3 + n3] = lds[e2r[w] + n3 * C::AZ];
         }
-        wave_sync();
+        frame_sync();
         float2 zp[P];
 #pragma unroll
         for (int w = 0; w < U3; ++w) {
@@ -456,6 +473,40 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const Stft
 #pragma unroll
             for (int k3 = 0; k3 < R3; ++k3) x[w * R3 + k3] = t[k3];
         }
+        if constexpr (C::PAIR) {
+            // ---- paired real-split post pass.  Bin k = ll + L*rho (rho = w + U3*k3).  A lane owns the pairs of its
+            // lower registers rho < P/2: (k, M-k); Z[M-k] is the upper register P-1-rho of lane L-ll (lane 0: its own
+            // register P-rho, and Z[M] = Z[0]).  With the window pre-scaled by 1/2 and T = (-i W_N^k) (Z[k] - conj Z[M-k]):
+            //     X[k] = S + T,   X[M-k] = conj(S - T),   S = Z[k] + conj Z[M-k]
+            // The self-paired bin M/2 (lane 0, register rho = P/2) is conj Z[M/2].  acc[j] = |X[ll + L j]|^2 (j < P/2),
+            // acc[P/2 + j] = |X[M - ll - L j]|^2, accNy = |X[M/2]|^2.
+            auto reg_of = [](int rho) { return (rho % U3) * R3 + rho / U3; };
+#pragma unroll
+            for (int rho = P / 2; rho < P; ++rho) lds[ll + L * rho] = x[reg_of(rho)];
+            if (ll == 0) lds[M] = x[0];   // Z[M] := Z[0]
+            frame_sync();
+            float2 zq[P / 2];
+#pragma unroll
+            for (int rho = 0; rho < P / 2; ++rho) zq[rho] = lds[M - (ll + L * rho)];
+            frame_sync();   // the next FFT's exchange stores must stay behind these loads
+#pragma unroll
+            for (int rho = 0; rho < P / 2; ++rho) {
+                const float2 z = x[reg_of(rho)], p = zq[rho];
+                const float2 S = make_float2(z.x + p.x, z.y - p.y);
+                const float2 D = make_float2(z.x - p.x, z.y + p.y);
+                const float2 W = JSG_T(rPost, tPost, reg_of(rho));
+                const float tx = W.x * D.x - W.y * D.y;
+                const float ty = W.x * D.y + W.y * D.x;
+                const float ax = S.x + tx, ay = S.y + ty;
+                const float bx = S.x - tx, by = S.y - ty;
+                acc[rho] = mix_combine<MIXOP>(acc[rho], ax * ax + ay * ay);
+                acc[P / 2 + rho] = mix_combine<MIXOP>(acc[P / 2 + rho], bx * bx + by * by);
+            }
+            {   // bin M/2 (meaningful in lane 0 only): the window carries 1/2, so |X|^2 = 4 |Z'|^2
+                const float2 z = x[reg_of(P / 2)];
+                accNy = mix_combine<MIXOP>(accNy, 4.0f * (z.x * z.x + z.y * z.y));
+            }
+        } else {
         // ---- partner fetch Z[M-k] for the real-split post pass ----
         if constexpr (C::ZX == 1) {
             // k = lane + 64 k3  ->  M-k = (64-lane) + 64 (7-k3): register 7-k3 of lane 64-lane; lane 0 pairs with
@@ -474,13 +525,13 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const Stft
                 for (int k3 = 0; k3 < R3; ++k3) lds[ll + L * w + R1 * R2 * k3] = x[w * R3 + k3];
             }
             if (ll == 0) lds[M] = x[0];   // Z[M] := Z[0]
-            wave_sync();
+            frame_sync();
 #pragma unroll
             for (int w = 0; w < U3; ++w) {
 #pragma unroll
                 for (int k3 = 0; k3 < R3; ++k3) zp[w * R3 + k3] = lds[M - (ll + L * w + R1 * R2 * k3)];
             }
-            wave_sync();   // the next FFT's exchange stores must stay behind these loads
+            frame_sync();   // the next FFT's exchange stores must stay behind these loads
         }
         // ---- real-split post pass: X[k] = (Z[k] + conj Z[M-k])/2 - i/2 W_N^k (Z[k] - conj Z[M-k]) ----
 #pragma unroll
@@ -497,6 +548,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const Stft
             const float d = x[0].x - x[0].y;
             accNy = mix_combine<MIXOP>(accNy, d * d);
         }
+        }   // !PAIR
         }   // ABL != 1
 
         // ---- last channel of this column: mix epilogue + dB + ring store ----
@@ -521,6 +573,24 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const Stft
                 for (int m = 0; m < P; ++m) acc[m] = to_db(acc[m]);
                 accNy = to_db(accNy);
             }
+            if constexpr (C::PAIR) {
+                if (C::ABL == 2 ? (acc[0] == 12345.678f) : (t < a.n_frames)) {
+#pragma unroll
+                    for (int rho = 0; rho < P / 2; ++rho) {
+                        if constexpr (C::NT) {
+                            __builtin_nontemporal_store(acc[rho], &dst[ll + L * rho]);
+                            __builtin_nontemporal_store(acc[P / 2 + rho], &dst[M - (ll + L * rho)]);
+                        } else {
+                            dst[ll + L * rho] = acc[rho];
+                            dst[M - (ll + L * rho)] = acc[P / 2 + rho];
+                        }
+                    }
+                    if (ll == 0) {
+                        if constexpr (C::NT) __builtin_nontemporal_store(accNy, &dst[M / 2]);
+                        else dst[M / 2] = accNy;
+                    }
+                }
+            } else
             if (C::ABL == 2 ? (acc[0] == 12345.678f) : (t < a.n_frames)) {
 #pragma unroll
                 for (int w = 0; w < U3; ++w) {
@@ -643,33 +713,35 @@ __global__ __launch_bounds__(256) void db_from_power_kernel(const float* p, floa
 // ------------------------------------------------------------------------------------------------------------
 template <class C>
 static void fill_tables(std::vector<float2>& t, const float* window, double amp) {
-    constexpr int L = C::L, P = C::P, R1 = C::R1, R2 = C::R2, R3 = C::R3, M = C::M, N = C::N;
-    t.assign(size_t(4) * P * 64, make_float2(0.f, 0.f));
+    constexpr int L = C::L, P = C::P, R1 = C::R1, R2 = C::R2, R3 = C::R3, M = C::M, N = C::N, TL = C::TL;
+    t.assign(size_t(4) * P * TL, make_float2(0.f, 0.f));
     const double two_pi = 6.283185307179586476925286766559;
-    for (int lane = 0; lane < 64; ++lane) {
-        const int ll = lane % L;
+    for (int e = 0; e < TL; ++e) {   // entry e of a table row belongs to lane-in-frame ll (L = 32: both half-waves)
+        const int ll = e % L;
         for (int m = 0; m < P; ++m) {   // window pairs: samples 2n, 2n+1 with n = ll + L m
             const int n = ll + L * m;
-            t[(0 * P + m) * 64 + lane] = make_float2(float(double(window[2 * n]) * amp), float(double(window[2 * n + 1]) * amp));
+            const double a2 = C::PAIR ? 0.5 * amp : amp;   // the paired post pass expects Z/2
+            t[(0 * P + m) * TL + e] = make_float2(float(double(window[2 * n]) * a2), float(double(window[2 * n + 1]) * a2));
         }
         for (int u = 0; u < C::U1; ++u)
             for (int k1 = 0; k1 < R1; ++k1) {
                 const int t1 = ll + L * u, n2 = t1 / R3;
                 const double ang = -two_pi * double((long long)n2 * k1 % (R1 * R2)) / double(R1 * R2);
-                t[(1 * P + u * R1 + k1) * 64 + lane] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
+                t[(1 * P + u * R1 + k1) * TL + e] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
             }
         for (int v = 0; v < C::U2; ++v)
             for (int k2 = 0; k2 < R2; ++k2) {
                 const int t2 = ll + L * v, k1 = t2 / R3, n3 = t2 % R3;
                 const double ang = -two_pi * double((long long)n3 * (k1 + R1 * k2) % M) / double(M);
-                t[(2 * P + v * R2 + k2) * 64 + lane] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
+                t[(2 * P + v * R2 + k2) * TL + e] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
             }
         for (int w = 0; w < C::U3; ++w)
             for (int k3 = 0; k3 < R3; ++k3) {
                 const int k = ll + L * w + R1 * R2 * k3;
                 const double ang = -two_pi * double(k) / double(N);
-                // -i/2 * exp(i ang) = 0.5 sin(ang) - 0.5 i cos(ang)
-                t[(3 * P + w * R3 + k3) * 64 + lane] = make_float2(float(0.5 * std::sin(ang)), float(-0.5 * std::cos(ang)));
+                // -i/2 * exp(i ang) = 0.5 sin(ang) - 0.5 i cos(ang); the paired post pass uses -i exp(i ang)
+                const double h = C::PAIR ? 1.0 : 0.5;
+                t[(3 * P + w * R3 + k3) * TL + e] = make_float2(float(h * std::sin(ang)), float(-h * std::cos(ang)));
             }
     }
 }

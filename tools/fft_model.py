@@ -19,7 +19,7 @@ LANES = 64
 
 class Plan:
     HALF_OFFSET = 0
-    def __init__(self, N, R1, R2, R3, S1=None, A=None, B=None, L=64):
+    def __init__(self, N, R1, R2, R3, S1=None, A=None, B=None, L=64, Z=1):
         global LANES
         LANES = L            # lanes that cooperate on one frame (64, or 32 = two frames per wave)
         self.L = L
@@ -34,7 +34,8 @@ class Plan:
         # exchange-2 layout: a2(k1,k2,n3) = k1*A + k2*B + n3
         self.B = B if B is not None else R3 + 1
         self.A = A if A is not None else R2 * self.B
-        self.lds_elems = max(R1 * self.S1, R1 * self.A, self.M + 1)
+        self.Z = Z
+        self.lds_elems = max((R1 - 1) * self.S1 + self.M // R1, (R1 - 1) * self.A + (R2 - 1) * self.B + (R3 - 1) * Z + 1, self.M + 1)
         Plan.HALF_OFFSET = self.lds_elems
 
     # ---- addresses (in complex-element units) -------------------------------------------------
@@ -42,7 +43,7 @@ class Plan:
         return k1 * self.S1 + t1
 
     def a2(self, k1, k2, n3):
-        return k1 * self.A + k2 * self.B + n3
+        return k1 * self.A + k2 * self.B + n3 * self.Z
 
     # ---- tables ------------------------------------------------------------------------------
     def tw1(self, u, k1, lane):
@@ -129,12 +130,16 @@ class Plan:
         if len(addrs) == 32:   # two frames per wave: the second half-wave uses a disjoint LDS region
             addrs = list(addrs) + [a + Plan.HALF_OFFSET for a in addrs]
         cyc = 0
-        for g in groups:
-            slots = {}
-            for l in g:
-                slots.setdefault(addrs[l] % mod, set()).add(addrs[l])
-            cyc += max(len(s) for s in slots.values())
-        return cyc, len(groups)
+        ideal = 0
+        for w0 in range(0, len(addrs), 64):   # frames spanning several wavefronts: one instruction per wavefront
+            wa = addrs[w0:w0 + 64]
+            for g in groups:
+                slots = {}
+                for l in g:
+                    slots.setdefault(wa[l] % mod, set()).add(wa[l])
+                cyc += max(len(s) for s in slots.values())
+            ideal += len(groups)
+        return cyc, ideal
 
     def conflicts(self, verbose=False):
         R1, R2, R3 = self.R
@@ -164,6 +169,7 @@ class Plan:
         R1, R2, R3 = self.R
         s1 = {self.a1(k1, t1) for k1 in range(R1) for t1 in range(self.M // R1)}
         s2 = {self.a2(k1, k2, n3) for k1 in range(R1) for k2 in range(R2) for n3 in range(R3)}
+        assert max(s2) < self.lds_elems and max(s1) < self.lds_elems
         return len(s1) == self.M and len(s2) == self.M
 
 
@@ -185,21 +191,22 @@ def search(N, R1, R2, R3, L=64):
     return best
 
 
-CONFIGS = {512: (8, 8, 4, 32), 1024: (8, 8, 8), 2048: (16, 8, 8), 4096: (8, 16, 16), 8192: (16, 16, 16)}
+# N: (R1, R2, R3, lanes per frame, S1, AX, AY, AZ) -- the plans compiled into jsg_kernels.hip
+CONFIGS = {512: (8, 8, 4, 32, 36, 4, 33, 1), 1024: (8, 8, 8, 64, 72, 9, 72, 2), 2048: (16, 8, 8, 64, 72, 65, 16, 2),
+           4096: (16, 8, 16, 128, 144, 1, 272, 17), 8192: (16, 16, 16, 256, 272, 1, 272, 17)}
 
 if __name__ == "__main__":
     rng = np.random.default_rng(0)
     for N, cfg in CONFIGS.items():
-        R1, R2, R3 = cfg[:3]
-        L = cfg[3] if len(cfg) > 3 else 64
+        R1, R2, R3, L, S1, AX, AY, AZ = cfg
         if len(sys.argv) > 1 and sys.argv[1] == "search":
             print(N, (R1, R2, R3), "best (cycles, lds_elems), (S1,A,B), ideal:", search(N, R1, R2, R3, L))
             continue
-        p = Plan(N, R1, R2, R3, L=L)
+        p = Plan(N, R1, R2, R3, S1=S1, A=AX, B=AY, L=L, Z=AZ)
         x = rng.standard_normal(N)
         ref = np.abs(np.fft.rfft(x)) ** 2
         got = p.run(x)
         err = np.max(np.abs(got - ref) / np.max(ref))
-        print(f"N={N} radices={(R1, R2, R3)} P={p.P} S1={p.S1} A={p.A} B={p.B} lds={p.lds_elems * 8} B "
+        print(f"N={N} radices={(R1, R2, R3)} L={L} P={p.P} S1={p.S1} AX={p.A} AY={p.B} AZ={p.Z} lds={p.lds_elems * 8} B "
               f"injective={p.check_injective()} max err={err:.2e}")
         p.conflicts(verbose=True)
