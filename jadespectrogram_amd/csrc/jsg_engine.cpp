@@ -12,6 +12,7 @@
 //   d_img   [H][W] uint32 ARGB     display image in ring order (x = ring column); the running-mode rotation is
 //                                  applied while copying out, so nothing is ever scrolled on the device.
 //   d_lut   [n_colors] int32       CColorPalette table.
+//   h_pin   (host, page-locked)    8 slots of [channels][n] floats: staging ring of processSynchronBlock.
 //
 // There is no CPU compute path here: without a usable HIP device every entry point reports an error.
 #include <hip/hip_runtime_api.h>
@@ -86,6 +87,14 @@ struct jsg_engine {
     int in_cap_blocks = 0;
     int mem_counter = 0;
     long long new_entry = kNewEntrySentinel;
+
+    // pinned staging ring of processSynchronBlock (audio thread): the block is copied into page-locked memory and
+    // leaves for the GPU with an asynchronous DMA, so the caller never waits for the device
+    static const int kPinSlots = 8;
+    float* h_pin = nullptr;
+    size_t pin_slot_floats = 0;
+    hipEvent_t pin_done[kPinSlots] = {};
+    unsigned pin_next = 0;
 
     // display
     int n_colors = 256, scheme = JSG_CM_JADE;   // CColorPalette(256,6), Spectrogram.cpp:337
@@ -182,6 +191,16 @@ int buildmem(jsg_engine* e) {
     e->in_cap_blocks = 0;
     int rc = ensure_input_capacity(e, 1, false);
     if (rc != JSG_OK) return rc;
+    const size_t slot = size_t(e->channels) * size_t(e->n);
+    if (slot != e->pin_slot_floats) {
+        if (e->h_pin) (void)hipHostFree(e->h_pin);
+        e->h_pin = nullptr;
+        e->pin_slot_floats = 0;
+        JSG_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_pin), slot * jsg_engine::kPinSlots * sizeof(float), hipHostMallocDefault));
+        e->pin_slot_floats = slot;
+    }
+    for (int i = 0; i < jsg_engine::kPinSlots; ++i)
+        if (!e->pin_done[i]) JSG_HIP(e, hipEventCreateWithFlags(&e->pin_done[i], hipEventDisableTiming));
     e->mem_counter = 0;
     e->new_entry = kNewEntrySentinel;
     return JSG_OK;
@@ -278,6 +297,9 @@ int jsg_destroy(jsg_engine* e) {
     if (e->d_in) (void)hipFree(e->d_in);
     if (e->d_lut) (void)hipFree(e->d_lut);
     if (e->d_img) (void)hipFree(e->d_img);
+    if (e->h_pin) (void)hipHostFree(e->h_pin);
+    for (int i = 0; i < jsg_engine::kPinSlots; ++i)
+        if (e->pin_done[i]) (void)hipEventDestroy(e->pin_done[i]);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return JSG_OK;
@@ -413,11 +435,17 @@ int jsg_process_block(jsg_engine* e, const float* const* planar) {
     if (!planar) return e->fail(JSG_ERR_INVALID, "null block");
     int rc = ensure_input_capacity(e, 1, true);
     if (rc != JSG_OK) return rc;
-    for (int c = 0; c < e->channels; ++c) {   // copy-in, reference Spectrogram.cpp:41-48
+    // copy-in (reference Spectrogram.cpp:41-48) through the pinned ring: host memcpy now, DMA later
+    const unsigned slot = e->pin_next++ % jsg_engine::kPinSlots;
+    JSG_HIP(e, hipEventSynchronize(e->pin_done[slot]));   // only waits if the GPU is 8 blocks behind
+    float* stage = e->h_pin + size_t(slot) * e->pin_slot_floats;
+    for (int c = 0; c < e->channels; ++c) {
         if (!planar[c]) return e->fail(JSG_ERR_INVALID, "null channel pointer");
-        JSG_HIP(e, hipMemcpyAsync(e->d_in + size_t(c) * e->in_pitch + e->n, planar[c], size_t(e->n) * 4,
-                                  hipMemcpyHostToDevice, e->stream));
+        std::memcpy(stage + size_t(c) * e->n, planar[c], size_t(e->n) * sizeof(float));
     }
+    JSG_HIP(e, hipMemcpy2DAsync(e->d_in + e->n, size_t(e->in_pitch) * 4, stage, size_t(e->n) * 4, size_t(e->n) * 4,
+                                size_t(e->channels), hipMemcpyHostToDevice, e->stream));
+    JSG_HIP(e, hipEventRecord(e->pin_done[slot], e->stream));
     return run_blocks(e, 1);
 }
 

@@ -661,39 +661,44 @@ __global__ __launch_bounds__(256) void colormap_kernel(const CmapKArgs a) {
     __shared__ unsigned short s_idx[CM_TILE][CM_TILE + 2];   // [bin][col]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool lut_in_lds = a.n_colors <= 1024;
-    if (lut_in_lds)
-        for (int i = tid; i < a.n_colors; i += 256) s_lut[i] = a.lut[i];
 
     const int col0 = blockIdx.x * CM_TILE;   // first column (relative to col_first) of this tile
     const int bin0 = blockIdx.y * CM_TILE;
-    // read phase: each wave takes 16 columns; lane = bin (256 B coalesced per column)
+    // read phase: each wave takes 16 columns; lane = bin (256 B coalesced per column).  All 16 loads are issued
+    // before the first use (one HBM round trip per tile instead of sixteen).
     const int bin = bin0 + lane;
-    for (int cc = wave; cc < CM_TILE; cc += 4) {
-        const int i = col0 + cc;
-        int idx = 0;
-        if (i < a.n_cols && bin < a.height) {
-            int col = a.col_first + i;
-            col %= a.ring_w;
-            const float v = a.db[(long long)col * a.db_pitch + bin];
-            idx = color_index(v, a.vmin, a.vmax, a.top, a.mult, a.n_colors);
-        }
-        s_idx[lane][cc] = (unsigned short)idx;
+    float v[CM_TILE / 4];
+#pragma unroll
+    for (int q = 0; q < CM_TILE / 4; ++q) {
+        const int i = col0 + wave + 4 * q;
+        int col = a.col_first + i;               // col_first < ring_w and i < n_cols <= ring_w
+        if (col >= a.ring_w) col -= a.ring_w;
+        v[q] = (i < a.n_cols && bin < a.height) ? a.db[(long long)col * a.db_pitch + bin] : 0.f;
     }
+    if (lut_in_lds)   // table load behind the tile loads: one latency, not two
+        for (int i = tid; i < a.n_colors; i += 256) s_lut[i] = a.lut[i];
+#pragma unroll
+    for (int q = 0; q < CM_TILE / 4; ++q)
+        s_idx[lane][wave + 4 * q] = (unsigned short)color_index(v[q], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
     __syncthreads();
     // write phase: each wave takes 16 image rows; lane = column (256 B coalesced per row when x does not wrap)
     const int i = col0 + lane;
-    int x = a.x_first + i;
+    int x = a.x_first + i;                       // x_first < x_wrap; wraps at most once when n_cols <= x_wrap
     x %= a.x_wrap;
-    for (int rr = wave; rr < CM_TILE; rr += 4) {
-        const int bb = bin0 + rr;
-        if (i < a.n_cols && bb < a.height) {
-            const int idx = s_idx[rr][lane];
-            const long long y = a.height - 1 - bb;          // low frequencies at the bottom (Spectrogram.cpp:642)
-            if (a.argb) {
-                const int rgb = lut_in_lds ? s_lut[idx] : a.lut[idx];
-                a.argb[y * a.argb_pitch + x] = (unsigned)rgb | 0xFF000000u;   // Spectrogram.cpp:637
+    if (i < a.n_cols) {
+#pragma unroll
+        for (int q = 0; q < CM_TILE / 4; ++q) {
+            const int rr = wave + 4 * q;
+            const int bb = bin0 + rr;
+            if (bb < a.height) {
+                const int idx = s_idx[rr][lane];
+                const long long y = a.height - 1 - bb;          // low frequencies at the bottom (Spectrogram.cpp:642)
+                if (a.argb) {
+                    const int rgb = lut_in_lds ? s_lut[idx] : a.lut[idx];
+                    __builtin_nontemporal_store((unsigned)rgb | 0xFF000000u, &a.argb[y * a.argb_pitch + x]);   // Spectrogram.cpp:637
+                }
+                if (a.index) a.index[y * a.index_pitch + x] = (unsigned char)idx;
             }
-            if (a.index) a.index[y * a.index_pitch + x] = (unsigned char)idx;
         }
     }
 }
@@ -966,6 +971,8 @@ int jsg_colormap_launch(const jsg_colormap_args* g, void* stream) {
     if (!g->db || !g->lut || g->height <= 0 || g->ring_width <= 0 || g->n_cols < 0 || g->x_wrap <= 0 ||
         g->n_colors <= 0 || g->col_first < 0 || g->x_first < 0 || (!g->argb_out && !g->index_out))
         return jsg_fail(JSG_ERR_INVALID, "jsg_colormap_launch: bad geometry");
+    if (g->n_cols > g->ring_width)
+        return jsg_fail(JSG_ERR_INVALID, "jsg_colormap_launch: more columns than the ring holds");
     if (g->index_out && g->n_colors > 256)
         return jsg_fail(JSG_ERR_INVALID, "jsg_colormap_launch: the 8-bit index plane needs n_colors <= 256");
     if (g->n_colors > 65535) return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_colormap_launch: n_colors > 65535");

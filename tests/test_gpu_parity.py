@@ -191,3 +191,24 @@ def test_unsupported_sizes_fail_loudly(jsg):
     with pytest.raises(jsg.JsgError):
         s.setMixMode(4)     # Right with one channel: out-of-bounds read in the reference
     s.close()
+
+
+def test_batch_larger_than_ring_keeps_newest_columns(jsg, oracle):
+    """One processBlocks call with more frames than ring columns: only the newest W columns survive, in ring order
+    (a single launch must never write one column twice)."""
+    C, n = 1, 1024
+    s = jsg.Spectrogram(C); o = oracle.OracleSpectrogram(C)
+    s.setSamplerate(48000.0); s.setmemoryTime_s(0.2); s.setFFTSize(n); s.setfeed_percent(2)
+    o.set_samplerate(48000.0); o.set_memory_time_s(0.2); o.set_fft_size(n); o.set_feed_percent(2)
+    W, H = s.getMemorySize(), s.getSpectrumSize()
+    assert W == o.memsize_blocks == 38
+    x = oracle.synth_audio(C, 25 * n, seed=13)          # 100 frames > 38 columns
+    s.processBlocks(x[:, :3 * n])                        # 12 columns first, so the ring position is not 0
+    s.processBlocks(x[:, 3 * n:])                        # 88 frames in one launch
+    for b in range(25):
+        o.process_synchron_block(x[:, b * n:(b + 1) * n])
+    mem = np.zeros((W, H), np.float32)
+    nv, pos = s.getMem(mem)
+    assert pos == o.mem_counter == 100 % W
+    assert np.abs(mem.astype(np.float64) - o.mem.astype(np.float64)).max() < 2e-3
+    s.close()
