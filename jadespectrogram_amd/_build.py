@@ -46,7 +46,8 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
             if src.endswith(".hip"):
                 # -fno-slp-vectorize: on gfx950 a packed v_pk_*_f32 costs two passes of the 32-wide SIMD, i.e. nothing
                 # is gained over two scalar ops, while the packing forces ~140 register moves per FFT
-                cmd += [f"--offload-arch={ARCH}", "-fno-slp-vectorize"]
+                # -amdgpu-kernarg-preload-count: the leading scalar kernel arguments are delivered in SGPRs
+                cmd += [f"--offload-arch={ARCH}", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
             else:
                 # host translation units: keep float arithmetic exactly as written (bit parity with the reference)
                 cmd += ["-ffp-contract=off", "-D__HIP_PLATFORM_AMD__"]

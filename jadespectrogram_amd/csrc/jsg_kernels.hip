@@ -233,7 +233,14 @@ __device__ __forceinline__ void swap_lane8(float& a, float& b, bool hi) {   // a
 
 // MIXOP: 0 sum (AbsMean, Left, Right, per-channel), 1 max, 2 min
 template <class C, int MIXOP>
-__global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(const StftKArgs a) {
+__global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
+    // the values the first loads depend on come first: with -amdgpu-kernarg-preload-count they arrive in SGPRs
+    // with the wave and the frame loads can be issued without a scalar-memory round trip
+    const float* __restrict__ k_in, const long long k_in_pitch, const unsigned k_n_frames, const unsigned k_first_frame,
+    const int k_hop, const int k_iters, const int k_flags, const int k_c_begin, const int k_c_end, const StftKArgs a_rest) {
+    StftKArgs a = a_rest;
+    a.in = k_in; a.in_pitch = k_in_pitch; a.n_frames = k_n_frames; a.first_frame = k_first_frame; a.hop = k_hop;
+    a.iters = k_iters; a.regular = k_flags & 1; a.per_channel = (k_flags >> 1) & 1; a.c_begin = k_c_begin; a.c_end = k_c_end;
     // Two distinct LDS objects on purpose: the (read-only) lane tables and the exchange buffers.  With one object
     // the compiler must assume that a table read may alias an exchange store and serialises them.
     __shared__ __attribute__((aligned(16))) float2 s_tab[C::TLOC == 1 ? C::TAB_ELEMS : 2];
@@ -763,7 +770,9 @@ static hipError_t launch_stft_mix(const StftKArgs& ka, dim3 grid, hipStream_t s)
         if (err != hipSuccess) return err;
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL((stft_db_kernel<C, MIXOP>), grid, dim3(C::WPB * 64), C::LDS_BYTES, s, ka);
+    const int flags = (ka.regular ? 1 : 0) | (ka.per_channel ? 2 : 0);
+    hipLaunchKernelGGL((stft_db_kernel<C, MIXOP>), grid, dim3(C::WPB * 64), C::LDS_BYTES, s, ka.in, ka.in_pitch, ka.n_frames,
+                       ka.first_frame, ka.hop, ka.iters, flags, ka.c_begin, ka.c_end, ka);
     return hipGetLastError();
 }
 
