@@ -212,3 +212,48 @@ def test_batch_larger_than_ring_keeps_newest_columns(jsg, oracle):
     assert pos == o.mem_counter == 100 % W
     assert np.abs(mem.astype(np.float64) - o.mem.astype(np.float64)).max() < 2e-3
     s.close()
+
+
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096, 8192])
+@pytest.mark.parametrize("frames", [1, 3, 17])
+def test_ragged_frame_counts(jsg, oracle, torch_cuda, n, frames):
+    """Frame counts that do not fill a workgroup (tail lanes duplicate the last frame and must not store)."""
+    torch = torch_cuda
+    hop = n // 4
+    x = oracle.synth_audio(2, (frames - 1) * hop + n, seed=frames, kind="noise")
+    win = oracle.window(oracle.WIN_HAMMING, n)
+    plan = jsg.Plan(n, win)
+    H = n // 2 + 1
+    d_out = torch.full((frames + 2, H + 3), 7.0, device="cuda")          # two guard columns, three guard bins
+    jsg.stft_db(plan, torch.from_numpy(x).cuda(), hop, frames, d_out[:frames + 0], feedblocks=4)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    assert (got[frames:] == 7.0).all() and (got[:, H:] == 7.0).all(), "stored outside the requested columns"
+    idx = (np.arange(frames) * hop)[:, None] + np.arange(n)[None, :]
+    fr = (x[:, idx] * win[None, None, :]).astype(np.float32)
+    pw = oracle.mix_channels(oracle.power_spectrum_f64(fr).astype(np.float32), oracle.MIX_ABSMEAN)
+    assert_db_close(got[:frames, :H], oracle.to_db(pw), pw.astype(np.float64), f"n={n} frames={frames}")
+
+
+def test_empty_inputs_and_bad_geometry(jsg, oracle, torch_cuda):
+    torch = torch_cuda
+    n = 1024
+    plan = jsg.Plan(n, oracle.window(1, n))
+    d_in = torch.zeros((1, 4 * n), device="cuda")
+    d_out = torch.full((4, 544), 3.0, device="cuda")
+    jsg.stft_db(plan, d_in, 512, 0, d_out)                                # zero frames: a no-op, not an error
+    torch.cuda.synchronize()
+    assert bool((d_out == 3.0).all())
+    with pytest.raises(jsg.JsgError):                                      # more frames than ring columns would race
+        jsg.stft_db(plan, d_in, 512, 5, d_out)
+    with pytest.raises(jsg.JsgError):                                      # column pitch smaller than n/2+1
+        jsg.stft_db(plan, d_in, 512, 2, torch.zeros((4, 512), device="cuda"))
+    s = jsg.Spectrogram(1)
+    s.setFFTSize(n)
+    assert s.processBlocks(np.zeros((1, 0), np.float32)) == 0             # empty batch
+    mem = np.zeros((s.getMemorySize(), 513), np.float32)
+    nv, pos = s.getMem(mem)
+    assert pos == 0 and (mem == np.float32(-120.0)).all()
+    with pytest.raises(jsg.JsgError):
+        s.processSynchronBlock(np.zeros((1, 1000), np.float32))           # not an fft-size block
+    s.close()
