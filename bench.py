@@ -29,8 +29,21 @@ ALGO_BYTES_PER_FRAME = 4 * HOP + 4 * H          # input count
 HBM_PEAK_GBS = 8000.0                           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def cpu_baseline(seconds_budget: float = 12.0):
-    """The oracle's CPU path timed on this host (rank 0, N=1 only): reported baseline, not the target."""
+def synth_audio(channels: int, n_samples: int, fs: float = 48000.0, seed: int = 1234):
+    """SURVEY 8d synthetic input: x_c[n] = 0.5 sin(2 pi f_c n / fs) + 0.1 u[n], f_c = 220*2^(c/12), u ~ U(-1,1)."""
+    import numpy as np
+    out = np.zeros((channels, n_samples), dtype=np.float32)
+    t = np.arange(n_samples, dtype=np.float64)
+    for c in range(channels):
+        u = np.random.default_rng(seed + c).uniform(-1.0, 1.0, n_samples)
+        out[c] = (0.5 * np.sin(2.0 * np.pi * 220.0 * 2.0 ** (c / 12.0) * t / fs) + 0.1 * u).astype(np.float32)
+    return out
+
+
+def cpu_baseline(seconds_budget: float = 12.0, check=None):
+    """The oracle's CPU path timed on this host (rank 0, N=1 only): reported baseline, not the target.
+    This leg is the only place where bench.py touches oracle/ (test infrastructure); `check` = (samples, dB) of a few
+    frames the GPU just produced, compared against the oracle before timing it."""
     import numpy as np
     from oracle import jsg_oracle as oracle
     try:
@@ -39,9 +52,13 @@ def cpu_baseline(seconds_budget: float = 12.0):
     except Exception:
         port = None
     win = oracle.window(oracle.WIN_HANN, N_FFT)
+    if check is not None:
+        x, got = check
+        fr = np.stack([x[j * HOP:j * HOP + N_FFT] * win for j in range(got.shape[0])]).astype(np.float32)
+        assert np.abs(got - oracle.to_db(oracle.power_spectrum(fr))).max() < 5e-3, "bench output drifted from the oracle"
     if port is not None:
         frames = 20000
-        x = oracle.synth_audio(1, frames * HOP + N_FFT)
+        x = synth_audio(1, frames * HOP + N_FFT)
         t0 = time.perf_counter(); done = 0
         while time.perf_counter() - t0 < seconds_budget:
             port.stft_db(x, N_FFT, HOP, frames, win)
@@ -51,7 +68,7 @@ def cpu_baseline(seconds_budget: float = 12.0):
                 "sample": f"{done} frames of the bench workload through oracle/jsg_oracle_c.c (scalar float32 C port "
                           f"of Spectrogram::processSynchronBlock, 1 thread) in {dt:.1f} s"}
     frames = 8192
-    x = oracle.synth_audio(1, frames * HOP + N_FFT)
+    x = synth_audio(1, frames * HOP + N_FFT)
     t0 = time.perf_counter(); done = 0
     while time.perf_counter() - t0 < seconds_budget:
         oracle.stft_db_reference(x[:, N_FFT:], N_FFT, HOP, 2, win)
@@ -73,7 +90,6 @@ def main():
     import numpy as np
     import torch
     import jadespectrogram_amd as jsg
-    from oracle import jsg_oracle as oracle   # synthetic input generator + cpu_baseline leg only
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -93,7 +109,7 @@ def main():
     n_samples = FRAMES * HOP + (N_FFT - HOP)
     pitch = (H + 31) // 32 * 32
     d_in, d_out = [], []
-    base = oracle.synth_audio(1, n_samples + args.nbuf * 64, seed=1234 + 1000 * rank)   # SURVEY 8d signal
+    base = synth_audio(1, n_samples + args.nbuf * 64, seed=1234 + 1000 * rank)   # SURVEY 8d signal
     for b in range(args.nbuf):
         d_in.append(torch.from_numpy(np.ascontiguousarray(base[:, b * 64:b * 64 + n_samples])).cuda())
         d_out.append(torch.empty((FRAMES, pitch), dtype=torch.float32, device="cuda"))
@@ -127,14 +143,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(t[0]), float(t[1])
 
-    # parity spot check of what was just timed (rank 0): dB column of the last batch vs the oracle
+    # what was just timed, for the parity spot check inside the cpu_baseline leg
+    check = None
     if rank == 0:
         b = (args.steps - 1) % args.nbuf
-        got = d_out[b][:4, :H].cpu().numpy()
-        x = d_in[b][0, :N_FFT + 3 * HOP].cpu().numpy()
-        fr = np.stack([x[j * HOP:j * HOP + N_FFT] * win for j in range(4)]).astype(np.float32)
-        ref = oracle.to_db(oracle.power_spectrum(fr))
-        assert np.abs(got - ref).max() < 5e-3, "bench output drifted from the oracle"
+        check = (d_in[b][0, :N_FFT + 3 * HOP].cpu().numpy(), d_out[b][:4, :H].cpu().numpy())
 
     # context for the roofline: a plain device-to-device copy of the SAME byte count (8.4 MB in, 8.4 MB out per launch),
     # rotating over the same number of distinct buffers -- what this launch size can reach at all on this GPU
@@ -187,7 +200,7 @@ def main():
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(check=check)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -257,3 +257,60 @@ def test_empty_inputs_and_bad_geometry(jsg, oracle, torch_cuda):
     with pytest.raises(jsg.JsgError):
         s.processSynchronBlock(np.zeros((1, 1000), np.float32))           # not an fft-size block
     s.close()
+
+
+def test_producer_and_consumer_threads(jsg, oracle):
+    """Audio thread (processSynchronBlock) and GUI thread (getMem) use one engine concurrently.  getMem copies only
+    the new columns into the caller's buffer, so after the run that buffer must hold the complete final ring (the
+    reference races here; the engine serialises producer and consumer internally)."""
+    import threading
+    C, n, K = 2, 1024, 60
+    x = oracle.synth_audio(C, K * n, seed=8)
+    s = jsg.Spectrogram(C)
+    s.setSamplerate(48000.0); s.setmemoryTime_s(0.5); s.setFFTSize(n); s.setfeed_percent(1)
+    W, H = s.getMemorySize(), s.getSpectrumSize()
+    assert 2 * K > W
+    mem = np.zeros((W, H), np.float32)
+    counts, stop = [], threading.Event()
+
+    def consumer():
+        while not stop.is_set():
+            nv, _ = s.getMem(mem)
+            counts.append(nv)
+
+    t = threading.Thread(target=consumer)
+    t.start()
+    for b in range(K):
+        assert s.processSynchronBlock(x[:, b * n:(b + 1) * n]) == 0
+    stop.set(); t.join()
+    nv, pos = s.getMem(mem)
+    counts.append(nv)
+    assert pos == (2 * K) % W
+    assert sum(c for c in counts if c < oracle.NEW_ENTRY_SENTINEL) <= 2 * K      # no column reported twice
+    ref = jsg.Spectrogram(C)
+    ref.setSamplerate(48000.0); ref.setmemoryTime_s(0.5); ref.setFFTSize(n); ref.setfeed_percent(1)
+    ref.processBlocks(x)
+    full = np.zeros((W, H), np.float32)
+    ref.getMem(full)
+    assert (mem.view(np.uint32) == full.view(np.uint32)).all()
+    s.close(); ref.close()
+
+
+def test_integration_md_ctypes_snippet(jsg):
+    """The raw-ctypes example of INTEGRATION.md section C, verbatim in spirit: plain C-ABI, no package helpers."""
+    import ctypes as C
+    lib = C.CDLL(jsg.capi.LIB_PATH)
+    h = C.c_void_p()
+    assert lib.jsg_create(C.byref(h), 2) == 0
+    assert lib.jsg_set_samplerate(h, C.c_float(48000.0)) == 0
+    assert lib.jsg_set_fft_size(h, 2048) == 0 and lib.jsg_set_feed_percent(h, 1) == 0
+    block = np.zeros((2, 2048), np.float32)
+    ptrs = (C.c_void_p * 2)(block[0].ctypes.data, block[1].ctypes.data)
+    assert lib.jsg_process_block(h, ptrs) == 0
+    W, H = lib.jsg_get_memory_size(h), lib.jsg_get_spectrum_size(h)
+    assert (W, H) == (47, 1025)
+    mem = np.zeros((W, H), np.float32); pos = C.c_int()
+    new_vals = lib.jsg_get_mem(h, mem.ctypes.data_as(C.c_void_p), W, C.byref(pos))
+    assert new_vals > W and pos.value == 2 and (mem[:2] == np.float32(-110.0)).all()
+    assert lib.jsg_get_mem(h, mem.ctypes.data_as(C.c_void_p), W + 1, C.byref(pos)) == -1
+    assert lib.jsg_destroy(h) == 0
