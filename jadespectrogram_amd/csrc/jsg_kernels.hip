@@ -173,7 +173,7 @@ using Cfg1024S = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 3>;
 using Cfg1024N = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 0, false>;
 using Cfg1024U = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 0, true, false>;
 using Cfg1024M = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 1, true>;
-using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 1, 1>;
+using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 1, 1>;   // (12-wave workgroups measured slower: 303 vs 410 Mframes/s)
 using Cfg4096 = Cfg<4096, 16, 8, 16, 128, 144, 1, 272, 17, 8, 1, 1, 0, 0, 1>;    // two wavefronts per frame
 using Cfg8192 = Cfg<8192, 16, 16, 16, 256, 272, 1, 272, 17, 8, 0, 1, 0, 0, 1>;   // four wavefronts per frame
 
@@ -291,14 +291,15 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
 
     // ---- lane tables first (L2-resident, 32 bytes per lane): their loads return before the frame's, so the
     //      LDS staging and the workgroup barrier finish while the frame loads are still in flight ----
-    constexpr int NTL = C::TLOC == 1 ? (C::TAB_ELEMS / 2) / (C::WPB * 64) : 1;   // 16-byte table loads per thread
-    static_assert(C::TLOC != 1 || (C::TAB_ELEMS / 2) % (C::WPB * 64) == 0, "table size must divide evenly over the workgroup");
+    constexpr int NTL = C::TLOC == 1 ? (C::TAB_ELEMS / 2 + C::WPB * 64 - 1) / (C::WPB * 64) : 1;   // 16-byte table loads per thread
+    constexpr bool TAB_EVEN = (C::TAB_ELEMS / 2) % (C::WPB * 64) == 0;
     typedef float v4f __attribute__((ext_vector_type(4)));
     v4f tabv[NTL];
     if constexpr (C::TLOC == 1) {
         const v4f* g4 = reinterpret_cast<const v4f*>(a.tab) + threadIdx.x;
 #pragma unroll
-        for (int i = 0; i < NTL; ++i) tabv[i] = g4[i * C::WPB * 64];
+        for (int i = 0; i < NTL; ++i)
+            if (TAB_EVEN || i + 1 < NTL || (int)threadIdx.x + i * C::WPB * 64 < C::TAB_ELEMS / 2) tabv[i] = g4[i * C::WPB * 64];
         __builtin_amdgcn_sched_barrier(0);   // keep the table loads OLDER than the frame loads (in-order vmcnt)
     }
     // ---- issue the loads of the first FFT(s) (software pipeline) ----
@@ -318,7 +319,8 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
     if constexpr (C::TLOC == 1) {
         v4f* s4 = reinterpret_cast<v4f*>(s_tab) + threadIdx.x;
 #pragma unroll
-        for (int i = 0; i < NTL; ++i) s4[i * C::WPB * 64] = tabv[i];
+        for (int i = 0; i < NTL; ++i)
+            if (TAB_EVEN || i + 1 < NTL || (int)threadIdx.x + i * C::WPB * 64 < C::TAB_ELEMS / 2) s4[i * C::WPB * 64] = tabv[i];
         __syncthreads();
         tWin = s_tab + tl;
     } else {
