@@ -96,12 +96,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    torch.cuda.set_device(local_rank)
+    # JSG_BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks (ranks then share devices);
+    # the driver's runs use the default: one rank per GPU, RCCL ("nccl") over xGMI
+    backend = os.environ.get("JSG_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     # ---- workload: NBUF independent mono batches per rank, resident in HBM ----
     win = jsg.window(jsg.capi.WIN_HANN, N_FFT)
@@ -139,7 +147,7 @@ def main():
     ev_ms = ev0.elapsed_time(ev1)                       # events on the stream the kernel runs on
 
     if dist is not None:
-        t = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall, ev_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(t[0]), float(t[1])
 
