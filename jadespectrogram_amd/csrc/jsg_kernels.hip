@@ -800,7 +800,37 @@ struct jsg_plan {
 
 static unsigned long long* g_dev_stamps = nullptr;
 
+// development only: tuned streaming copy, the physical floor for "move these bytes once" at a given launch size
+template <bool NT>
+__global__ __launch_bounds__(256) void dev_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f* s = reinterpret_cast<const v4f*>(src);
+    v4f* d = reinterpret_cast<v4f*>(dst);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const v4f a = s[i], b = s[i + stride], c = s[i + 2 * stride], e = s[i + 3 * stride];
+        if (NT) {
+            __builtin_nontemporal_store(a, &d[i]); __builtin_nontemporal_store(b, &d[i + stride]);
+            __builtin_nontemporal_store(c, &d[i + 2 * stride]); __builtin_nontemporal_store(e, &d[i + 3 * stride]);
+        } else { d[i] = a; d[i + stride] = b; d[i + 2 * stride] = c; d[i + 3 * stride] = e; }
+    }
+    for (; i < n4; i += stride) {
+        if (NT) __builtin_nontemporal_store(s[i], &d[i]); else d[i] = s[i];
+    }
+}
+
 extern "C" {
+
+// development only (not part of include/jsg.h): streaming copy microbenchmark (tools/copy_floor.py)
+int jsg_dev_copy_launch(const void* src, void* dst, long long bytes, int blocks, int nt, void* stream) {
+    const long long n4 = bytes / 16;
+    if (nt) hipLaunchKernelGGL(dev_copy_kernel<true>, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                               static_cast<const float4*>(src), static_cast<float4*>(dst), n4);
+    else hipLaunchKernelGGL(dev_copy_kernel<false>, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                            static_cast<const float4*>(src), static_cast<float4*>(dst), n4);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
 
 // development only (not part of include/jsg.h): device buffer for the s_memtime stamps of variant 'S'
 void jsg_dev_set_stamp_buffer(void* p) { g_dev_stamps = static_cast<unsigned long long*>(p); }
@@ -864,6 +894,11 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: bad geometry");
     if (g->n_frames > g->ring_width)
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: more frames than ring columns in one launch (columns would race)");
+    {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev != plan->device)
+            return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: the plan was created on another device");
+    }
     if (g->n_frames >= (1ll << 31) || g->first_frame + g->n_frames >= (1ll << 31))
         return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_db_launch: frame index does not fit 31 bits");
     StftKArgs ka{};

@@ -226,10 +226,37 @@ class Plan:
             pass
 
 
+class StftLaunch:
+    """A prepared launch: the argument block is filled once, `launch(stream)` is then a single FFI call
+    (the per-call Python work of stft_db() is ~2 us, comparable to a short kernel)."""
+
+    def __init__(self, plan: Plan, d_in, hop: int, n_frames: int, d_out, **kw):
+        self._plan = plan
+        self._keep = (d_in, d_out)
+        self._args = _stft_args(plan, d_in, hop, n_frames, d_out, **kw)
+        self._ref = C.byref(self._args)
+        self._fn = lib().jsg_stft_db_launch
+
+    def launch(self, stream: int):
+        rc = self._fn(self._plan._p, self._ref, stream)
+        if rc < 0:
+            check(rc)
+
+
 def stft_db(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: int | None = None, mix_mode: int = 0,
             first_frame: int = 0, ring_pos: int = 0, linear_out: bool = False, stream: int | None = None):
     """Enqueue one fused STFT->dB launch.  d_in: torch CUDA float32 [C][samples]; d_out: [W][pitch] (or
     [C][W][pitch] with mix_mode PER_CHANNEL).  Frame j starts at sample (j//feedblocks)*n + (j%feedblocks)*hop."""
+    import torch
+    a = _stft_args(plan, d_in, hop, n_frames, d_out, feedblocks=feedblocks, mix_mode=mix_mode, first_frame=first_frame,
+                   ring_pos=ring_pos, linear_out=linear_out)
+    if stream is None:
+        stream = torch.cuda.current_stream(d_in.device).cuda_stream
+    check(lib().jsg_stft_db_launch(plan._p, C.byref(a), C.c_void_p(stream)))
+
+
+def _stft_args(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: int | None = None, mix_mode: int = 0,
+               first_frame: int = 0, ring_pos: int = 0, linear_out: bool = False):
     import torch
     assert d_in.is_cuda and d_in.dtype == torch.float32 and d_in.dim() == 2 and d_in.stride(1) == 1
     assert d_out.is_cuda and d_out.dtype == torch.float32 and d_out.stride(-1) == 1
@@ -248,9 +275,7 @@ def stft_db(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: int
     a.ring_width = d_out.shape[-2]
     a.ring_pos = ring_pos
     a.linear_out = int(bool(linear_out))
-    if stream is None:
-        stream = torch.cuda.current_stream(d_in.device).cuda_stream
-    check(lib().jsg_stft_db_launch(plan._p, C.byref(a), C.c_void_p(stream)))
+    return a
 
 
 def colormap(d_db, d_lut, lo: float, hi: float, *, d_argb=None, d_index=None, col_first: int = 0, n_cols: int | None = None,
