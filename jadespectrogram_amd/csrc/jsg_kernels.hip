@@ -130,7 +130,9 @@ struct Cfg {
     // its lower P/2 registers and stores both bins (8 fewer VALU ops per pair, half the partner fetches).
     static constexpr bool PAIR = PAIR_ && ZX_ == 0;
     static constexpr bool NT = NT_;                  // non-temporal (streaming) stores of the dB columns
-    static constexpr int ABL = ABL_;                 // development ablations: 1 = memory traffic only, 2 = compute only
+    static constexpr int ABLX = ABL_;                // development ablations: 1 = memory traffic only, 2 = compute only, 3 = stamps,
+                                                     // 11..14 = memory-only sub-modes (no table staging / half loads / 16-B stores / all)
+    static constexpr int ABL = ABL_ >= 11 ? 1 : ABL_;
     static constexpr int XCH1 = XCH1_, ZX = ZX_;
     static constexpr int PF = PF_;                   // software-prefetch depth in FFTs (1 or 2)
     static constexpr int N = N_, M = N_ / 2, R1 = R1_, R2 = R2_, R3 = R3_, L = L_;
@@ -169,6 +171,10 @@ using Cfg1024E = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 4, 1, 2, 0, 0, 1>;
 using Cfg1024F = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 16, 1, 4, 0, 0, 1>;
 using Cfg1024G = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 1>;
 using Cfg1024H = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 2>;
+using Cfg1024G1 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 0, 2, 0, 0, 1, 11>;
+using Cfg1024G2 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 12>;
+using Cfg1024G3 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 13>;
+using Cfg1024G4 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 0, 2, 0, 0, 1, 14>;
 using Cfg1024S = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 3>;
 using Cfg1024N = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 0, false>;
 using Cfg1024U = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 0, true, false>;
@@ -307,7 +313,10 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
     if constexpr (C::PF > 0 && C::ABL != 2) {
         const f2u* src = frame_src(0);
 #pragma unroll
-        for (int m = 0; m < P; ++m) rawA[m] = src[L * m];
+        for (int m = 0; m < P; ++m) {
+            if ((C::ABLX == 12 || C::ABLX == 14) && m < P / 2) { rawA[m].x = 1.f; rawA[m].y = 2.f; }
+            else rawA[m] = src[L * m];
+        }
         if (C::PF == 2 && n_fft > 1) {
             const f2u* src1 = frame_src(1);
 #pragma unroll
@@ -387,7 +396,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
         }
 #pragma unroll
         for (int m = 0; m < P; ++m) {
-            const float2 w = JSG_T(rWin, tWin, m);
+            const float2 w = (C::ABLX == 11 || C::ABLX == 14) ? make_float2(0.5f, 0.25f) : JSG_T(rWin, tWin, m);
             x[m] = make_float2(raw[m].x * w.x, raw[m].y * w.y);
         }
         if constexpr (C::ABL == 3) {
@@ -397,7 +406,10 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
         if (C::ABL != 2 && C::PF > 0 && s + C::PF < n_fft) {
             const f2u* src = frame_src(s + C::PF);
 #pragma unroll
-            for (int m = 0; m < P; ++m) raw[m] = src[L * m];
+            for (int m = 0; m < P; ++m) {
+                if ((C::ABLX == 12 || C::ABLX == 14) && m < P / 2) { raw[m].x = 1.f; raw[m].y = 2.f; }
+                else raw[m] = src[L * m];
+            }
         }
         if constexpr (C::ABL == 1) {   // ablation: memory traffic only (results are meaningless)
 #pragma unroll
@@ -582,7 +594,17 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
                 for (int m = 0; m < P; ++m) acc[m] = to_db(acc[m]);
                 accNy = to_db(accNy);
             }
-            if constexpr (C::PAIR) {
+            if constexpr (C::ABLX == 13 || C::ABLX == 14) {
+                // ablation: the same bytes as two 16-byte stores per lane (results meaningless)
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                if (t < a.n_frames) {
+                    v4f* d4 = reinterpret_cast<v4f*>(dst);
+                    v4f v0 = {acc[0], acc[1], acc[2], acc[3]}, v1 = {acc[4], acc[5], acc[6], acc[7]};
+                    __builtin_nontemporal_store(v0, &d4[ll]);
+                    __builtin_nontemporal_store(v1, &d4[64 + ll]);
+                    if (ll == 0) __builtin_nontemporal_store(accNy, &dst[M]);
+                }
+            } else if constexpr (C::PAIR) {
                 if (C::ABL == 2 ? (acc[0] == 12345.678f) : (t < a.n_frames)) {
 #pragma unroll
                     for (int rho = 0; rho < P / 2; ++rho) {
@@ -985,6 +1007,10 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
                 case 'F': err = launch_stft<Cfg1024F>(ka, mixop, grid, s); break;
                 case 'G': err = launch_stft<Cfg1024G>(ka, mixop, grid, s); break;
                 case 'H': err = launch_stft<Cfg1024H>(ka, mixop, grid, s); break;
+                case '1': err = launch_stft<Cfg1024G1>(ka, mixop, grid, s); break;
+                case '2': err = launch_stft<Cfg1024G2>(ka, mixop, grid, s); break;
+                case '3': err = launch_stft<Cfg1024G3>(ka, mixop, grid, s); break;
+                case '4': err = launch_stft<Cfg1024G4>(ka, mixop, grid, s); break;
                 case 'S': err = launch_stft<Cfg1024S>(ka, mixop, grid, s); break;
                 case 'N': err = launch_stft<Cfg1024N>(ka, mixop, grid, s); break;
                 case 'M': err = launch_stft<Cfg1024M>(ka, mixop, grid, s); break;
