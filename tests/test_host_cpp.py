@@ -56,3 +56,11 @@ def test_dropin_plugin_call_sequence(jsg, oracle):
     assert (img == oracle.render_all(mem, info["pos"], pal, running=True)).all()
     assert info["rgb0"] == int(pal.get_rgb_color(np.float32([-200.0]))[0])
     assert info["rgb_mid"] == int(pal.get_rgb_color(np.float32([0.0]))[0])
+
+
+def test_reblocker_stand_in_cpu():
+    """SynchronBlockProcessor stand-in: host blocks of any size -> fixed fft-size blocks, sample order preserved."""
+    exe = os.path.join(tempfile.gettempdir(), "jsg_reblocker_test")
+    src = os.path.join(ROOT, "tests", "cpp", "reblocker_test.cpp")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", src, "-o", exe])
+    assert subprocess.call([exe]) == 0
