@@ -227,6 +227,20 @@ int jsg_display_invalidate(jsg_engine* e);
 int jsg_display_update(jsg_engine* e, float min_color, float max_color, uint32_t* argb, int64_t pitch,
                        int* new_vals, int* pos);
 
+/* Incremental tick for hosts that scroll their own image like the reference (moveImageSection + fill of the
+ * right-most columns, Spectrogram.cpp:663-683): colours only the new columns and copies just them into `tile`
+ * ([height][tile_pitch] pixels, oldest column first).  Returns 0 and *new_vals (<= max_cols) columns; returns 1
+ * (nothing consumed) when a full recolour is pending or more than max_cols columns are new -- then call
+ * jsg_display_update for the whole image. */
+int jsg_display_update_tile(jsg_engine* e, float min_color, float max_color, uint32_t* tile, int64_t tile_pitch,
+                            int max_cols, int* new_vals, int* pos);
+
+/* The frequency window of SpectrogramComponent::paint (Spectrogram.cpp:441-459): which image rows show
+ * [min_freq, max_freq] Hz.  Pure host arithmetic (same clamps and roundings); outputs displayStartPixel,
+ * displayEndPixel, heightInterval and hStart (= height - displayEndPixel, the first image row to blit). */
+int jsg_display_freq_rows(float fs, int height, float min_freq, float max_freq, int* start_pixel, int* end_pixel,
+                          int* height_interval, int* h_start);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,6 +100,10 @@ SIGNATURES = {
     "jsg_display_set_running": (C.c_int, [_P, C.c_int]),
     "jsg_display_invalidate": (C.c_int, [_P]),
     "jsg_display_update": (C.c_int, [_P, C.c_float, C.c_float, _P, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "jsg_display_update_tile": (C.c_int, [_P, C.c_float, C.c_float, _P, C.c_int64, C.c_int, C.POINTER(C.c_int),
+                                          C.POINTER(C.c_int)]),
+    "jsg_display_freq_rows": (C.c_int, [C.c_float, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
 
 _lib = None

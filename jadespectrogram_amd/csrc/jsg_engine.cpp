@@ -618,4 +618,53 @@ int jsg_display_update(jsg_engine* e, float min_color, float max_color, uint32_t
     return JSG_OK;
 }
 
+int jsg_display_update_tile(jsg_engine* e, float min_color, float max_color, uint32_t* tile, int64_t tile_pitch,
+                            int max_cols, int* new_vals, int* pos_out) {
+    JSG_LOCK(e);
+    if (e->mix == JSG_MIX_PER_CHANNEL) return e->fail(JSG_ERR_UNSUPPORTED, "display needs a mixed (single) spectrogram");
+    const int W = e->W, H = e->H;
+    if (!tile || max_cols <= 0 || tile_pitch < max_cols) return e->fail(JSG_ERR_INVALID, "bad tile buffer");
+    const long long nec = e->new_entry;
+    if (e->recompute_all || W != e->img_w || H != e->img_h || nec > W || nec > max_cols) {
+        if (new_vals) *new_vals = int(std::min<long long>(nec, 2000000000ll));
+        if (pos_out) *pos_out = e->mem_counter;
+        return 1;   // the caller needs the whole image: jsg_display_update
+    }
+    e->new_entry = 0;
+    const int pos = e->mem_counter;
+    const int nv = int(nec);
+    if (nv > 0) {
+        jsg_colormap_args a{};
+        a.db = e->d_ring;
+        a.db_pitch = e->pitch;
+        a.ring_width = W;
+        a.height = H;
+        a.x_wrap = W;
+        a.lut = e->d_lut;
+        a.n_colors = e->n_colors;
+        jsg_colormap_range(e->n_colors, min_color, max_color, &a.vmin, &a.vmax, &a.access_mult);
+        a.argb_out = e->d_img;
+        a.argb_pitch = W;
+        a.n_cols = nv;
+        a.col_first = ((pos - nv) % W + W) % W;
+        a.x_first = a.col_first;
+        const int rc = jsg_colormap_launch(&a, e->stream);
+        if (rc != JSG_OK) {
+            e->err = tls_error();
+            return rc;
+        }
+        const int first = a.col_first;
+        const int n1 = std::min(nv, W - first);   // columns before the ring wraps
+        JSG_HIP(e, hipMemcpy2DAsync(tile, size_t(tile_pitch) * 4, e->d_img + first, size_t(W) * 4, size_t(n1) * 4, size_t(H),
+                                    hipMemcpyDeviceToHost, e->stream));
+        if (nv > n1)
+            JSG_HIP(e, hipMemcpy2DAsync(tile + n1, size_t(tile_pitch) * 4, e->d_img, size_t(W) * 4, size_t(nv - n1) * 4,
+                                        size_t(H), hipMemcpyDeviceToHost, e->stream));
+        JSG_HIP(e, hipStreamSynchronize(e->stream));
+    }
+    if (new_vals) *new_vals = nv;
+    if (pos_out) *pos_out = pos;
+    return JSG_OK;
+}
+
 }  // extern "C"

@@ -190,4 +190,21 @@ int jsg_colormap_range(int n_colors, float lo, float hi, float* vmin, float* vma
     return JSG_OK;
 }
 
+int jsg_display_freq_rows(float fs, int height, float min_freq, float max_freq, int* start_pixel, int* end_pixel,
+                          int* height_interval, int* h_start) {
+    if (!(fs > 0.f) || height <= 0) return JSG_ERR_INVALID;
+    float mn = min_freq, mx = max_freq;
+    if (double(mn) >= double(fs) * 0.5) mn = float(0.9 * double(fs) * 0.5);   // Spectrogram.cpp:444-445
+    if (double(mx) >= double(fs) * 0.5) mx = float(double(fs) * 0.5);         // :446-447
+    if (mn >= mx) mn = float(0.9 * double(mx));                               // :449-453
+    const double lo = 2.0 * double(mn) / double(fs) * double(height);
+    const double hi = 2.0 * double(mx) / double(fs) * double(height);
+    const int start = int(lo + 0.5), end = int(hi + 0.5);                     // :455-456
+    if (start_pixel) *start_pixel = start;
+    if (end_pixel) *end_pixel = end;
+    if (height_interval) *height_interval = int(hi - lo + 0.5);               // :457
+    if (h_start) *h_start = height - end;                                     // :459
+    return JSG_OK;
+}
+
 }  // extern "C"

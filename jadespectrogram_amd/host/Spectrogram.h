@@ -128,6 +128,17 @@ public:
     int update(float minColor, float maxColor, uint32_t* argb, int64_t pitchPixels, int& newVals, int& pos) {
         return jsg_display_update(m_spec.engine(), minColor, maxColor, argb, pitchPixels, &newVals, &pos);
     }
+    // Incremental variant for hosts that keep the reference's scroll (m_internalImg.moveImageSection, Spectrogram.cpp:665):
+    // fills `tile` ([height][pitch], oldest column first) with the newVals newest columns; returns 1 when the whole
+    // image has to be redrawn through update() instead (colour range / scheme changed, or more than maxCols are new).
+    int updateTile(float minColor, float maxColor, uint32_t* tile, int64_t pitchPixels, int maxCols, int& newVals, int& pos) {
+        return jsg_display_update_tile(m_spec.engine(), minColor, maxColor, tile, pitchPixels, maxCols, &newVals, &pos);
+    }
+    // the rows paint() blits for [minFreq, maxFreq] (reference Spectrogram.cpp:441-459)
+    static void freqRows(float fs, int height, float minFreq, float maxFreq, int& startPixel, int& endPixel,
+                         int& heightInterval, int& hStart) {
+        jsg_display_freq_rows(fs, height, minFreq, maxFreq, &startPixel, &endPixel, &heightInterval, &hStart);
+    }
 
 private:
     Spectrogram& m_spec;

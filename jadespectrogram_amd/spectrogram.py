@@ -180,6 +180,23 @@ class SpectrogramDisplay:
         return nv.value, pos.value
 
 
+    def timerCallbackTile(self, tile: np.ndarray, min_color=-50.0, max_color=50.0):
+        """Incremental tick: only the new columns, as a [H][max_cols] tile (oldest first).  Returns
+        (need_full, newVals, pos); need_full=True means call timerCallback() for the whole image instead."""
+        assert tile.dtype == np.uint32 and tile.ndim == 2 and tile.strides[1] == 4
+        nv, pos = C.c_int(), C.c_int()
+        rc = self.spec._c(lib().jsg_display_update_tile(self.spec._h, min_color, max_color, tile.ctypes.data,
+                                                        tile.strides[0] // 4, tile.shape[1], C.byref(nv), C.byref(pos)))
+        return rc == 1, nv.value, pos.value
+
+
+def display_freq_rows(fs: float, height: int, min_freq: float, max_freq: float):
+    """paint()'s frequency window (reference Spectrogram.cpp:441-459): (startPixel, endPixel, heightInterval, hStart)."""
+    a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    check(lib().jsg_display_freq_rows(fs, height, min_freq, max_freq, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+    return a.value, b.value, c.value, d.value
+
+
 class CColorPalette:
     """Host mirror of the reference's CColorPalette: table + range on the host, bulk mapping on the GPU."""
     kMono, kBW, kHot, kRainbow, kViridis, kPlasma, kJade = range(7)

@@ -487,6 +487,21 @@ class OracleDisplay:
         return new_vals, pos
 
 
+def display_freq_rows(fs, height: int, min_freq, max_freq):
+    """The sub-rectangle selection of SpectrogramComponent::paint (Spectrogram.cpp:441-459)."""
+    fs, mn, mx = f32(fs), f32(min_freq), f32(max_freq)
+    if float(mn) >= float(fs) * 0.5:
+        mn = f32(0.9 * float(fs) * 0.5)                                          # :444-445
+    if float(mx) >= float(fs) * 0.5:
+        mx = f32(float(fs) * 0.5)                                                # :446-447
+    if mn >= mx:
+        mn = f32(0.9 * float(mx))                                                # :451
+    lo = 2.0 * float(mn) / float(fs) * height
+    hi = 2.0 * float(mx) / float(fs) * height
+    start, end = int(lo + 0.5), int(hi + 0.5)                                    # :455-456
+    return start, end, int(hi - lo + 0.5), height - end                          # :457, :459
+
+
 def render_all(db_ring: np.ndarray, pos: int, palette: OracleColorPalette, running: bool = True) -> np.ndarray:
     """Closed form of the recompute-all branch (Spectrogram.cpp:623-657) for a [W][H] dB ring."""
     W, H = db_ring.shape

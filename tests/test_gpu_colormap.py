@@ -141,3 +141,35 @@ def test_display_exact_given_gpu_db(jsg, oracle):
         pal = oracle.OracleColorPalette(256, scheme); pal.set_value_range(lo, hi)
         assert (img == oracle.render_all(mem, pos, pal, running=True)).all()
     s.close()
+
+
+def test_display_tile_updates_match_full_image(jsg, oracle):
+    """Incremental tile ticks (host scrolls its own image like the reference) stay equal to a full recolour."""
+    C, n = 1, 1024
+    s = jsg.Spectrogram(C)
+    s.setSamplerate(48000.0); s.setmemoryTime_s(0.4); s.setFFTSize(n); s.setfeed_percent(1)
+    W, H = s.getMemorySize(), s.getSpectrumSize()
+    d = jsg.SpectrogramDisplay(s)
+    x = oracle.synth_audio(C, 70 * n, seed=17)
+    img = np.zeros((H, W), np.uint32)
+    tile = np.zeros((H, 16), np.uint32)
+    need_full, nv, pos = d.timerCallbackTile(tile)
+    assert need_full                                             # first tick: full recolour pending
+    d.timerCallback(img)
+    blocks = 0
+    for nb in (2, 3, 0, 5, 1, 7):
+        for _ in range(nb):
+            s.processSynchronBlock(x[:, blocks * n:(blocks + 1) * n]); blocks += 1
+        need_full, nv, pos = d.timerCallbackTile(tile)
+        assert not need_full and nv == 2 * nb
+        if nv:                                                   # reference Spectrogram.cpp:665-682
+            img[:, :W - nv] = img[:, nv:].copy()
+            img[:, W - nv:] = tile[:, :nv]
+        full = np.zeros((H, W), np.uint32)
+        d.invalidate(); d.timerCallback(full)                    # ground truth: recolour everything
+        assert (img == full).all()
+    for _ in range(12):                                          # 24 new columns > 16-column tile
+        s.processSynchronBlock(x[:, blocks * n:(blocks + 1) * n]); blocks += 1
+    need_full, nv, pos = d.timerCallbackTile(tile)
+    assert need_full and nv == 24
+    s.close()

@@ -84,3 +84,17 @@ def test_no_cpu_fallback(jsg):
     assert ei.value.code == jsg.capi.JSG_ERR_NO_DEVICE
     with pytest.raises(jsg.JsgError):
         jsg.Plan(1024, jsg.window(1, 1024))
+
+
+def test_display_freq_rows_vs_oracle(jsg, oracle):
+    from jadespectrogram_amd.spectrogram import display_freq_rows
+    rng = np.random.default_rng(5)
+    cases = [(48000.0, 1025, 1.0, 20000.0), (48000.0, 1025, 0.0, 24000.0), (44100.0, 513, 30000.0, 40000.0),
+             (96000.0, 2049, 5000.0, 100.0), (48000.0, 1025, 1000.0, 1000.0)]
+    for _ in range(300):
+        cases.append((float(rng.choice([44100.0, 48000.0, 96000.0])), int(rng.choice([257, 513, 1025, 2049, 4097])),
+                      float(np.exp(rng.uniform(0.0, np.log(10000.0)))), float(np.exp(rng.uniform(np.log(500.0), np.log(20000.0))))))
+    for c in cases:
+        assert display_freq_rows(*c) == oracle.display_freq_rows(*c), c
+    # the plugin's defaults: full band at 48 kHz, H = 1025 -> rows [0, 854): everything up to 20 kHz
+    assert display_freq_rows(48000.0, 1025, 1.0, 20000.0) == (0, 854, 854, 171)
