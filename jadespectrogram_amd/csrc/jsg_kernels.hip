@@ -15,6 +15,7 @@
 // The index algebra, the twiddle tables and the LDS layouts are modelled and checked in tools/fft_model.py.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -165,10 +166,7 @@ using Cfg512 = Cfg<512, 8, 8, 4, 32, 36, 4, 33, 1, 8, 1, 2, 0, 0, 1>;
 using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1>;
 // development variants of the 1024-point plan (selected with JSG_1024_VARIANT, see tools/sweep_variants.sh)
 using Cfg1024B = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 0, 2>;
-using Cfg1024C = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 2>;
 using Cfg1024D = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 1, 1>;
-using Cfg1024E = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 4, 1, 2, 0, 0, 1>;
-using Cfg1024F = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 16, 1, 4, 0, 0, 1>;
 using Cfg1024G = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 1>;
 using Cfg1024H = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 2>;
 using Cfg1024G1 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 0, 2, 0, 0, 1, 11>;
@@ -784,15 +782,15 @@ static void fill_tables(std::vector<float2>& t, const float* window, double amp)
 
 template <class C, int MIXOP>
 static hipError_t launch_stft_mix(const StftKArgs& ka, dim3 grid, hipStream_t s) {
-    static bool attr_done[64] = {};
+    static std::atomic<bool> attr_done[64];   // set once per device; setting it twice from two threads is harmless
     int dev = 0;
     hipError_t err = hipGetDevice(&dev);
     if (err != hipSuccess) return err;
-    if (C::LDS_BYTES > 48 * 1024 && dev < 64 && !attr_done[dev]) {
+    if (C::LDS_BYTES > 48 * 1024 && dev >= 0 && dev < 64 && !attr_done[dev].load(std::memory_order_acquire)) {
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_db_kernel<C, MIXOP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (err != hipSuccess) return err;
-        attr_done[dev] = true;
+        attr_done[dev].store(true, std::memory_order_release);
     }
     const int flags = (ka.regular ? 1 : 0) | (ka.per_channel ? 2 : 0);
     hipLaunchKernelGGL((stft_db_kernel<C, MIXOP>), grid, dim3(C::WPB * 64), C::LDS_BYTES, s, ka.in, ka.in_pitch, ka.n_frames,
@@ -973,7 +971,8 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
         case 512: tpb = Cfg512::TPB; break;
         case 1024: {
             const char* e = getenv("JSG_1024_VARIANT");
-            tpb = (e && e[0] == 'E') ? Cfg1024E::TPB : (e && e[0] == 'F') ? Cfg1024F::TPB : Cfg1024::TPB;
+            (void)e;
+            tpb = Cfg1024::TPB;
             break;
         }
         case 2048: tpb = Cfg2048::TPB; break;
@@ -1001,10 +1000,7 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
             static const int variant = [] { const char* e = getenv("JSG_1024_VARIANT"); return e ? e[0] : '-'; }();
             switch (variant) {
                 case 'B': err = launch_stft<Cfg1024B>(ka, mixop, grid, s); break;
-                case 'C': err = launch_stft<Cfg1024C>(ka, mixop, grid, s); break;
                 case 'D': err = launch_stft<Cfg1024D>(ka, mixop, grid, s); break;
-                case 'E': err = launch_stft<Cfg1024E>(ka, mixop, grid, s); break;
-                case 'F': err = launch_stft<Cfg1024F>(ka, mixop, grid, s); break;
                 case 'G': err = launch_stft<Cfg1024G>(ka, mixop, grid, s); break;
                 case 'H': err = launch_stft<Cfg1024H>(ka, mixop, grid, s); break;
                 case '1': err = launch_stft<Cfg1024G1>(ka, mixop, grid, s); break;
