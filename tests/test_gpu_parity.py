@@ -55,6 +55,10 @@ CASES = [
     (1024, 3, 2, 0, 1),      # perc10: irregular hop 102 x9 + 106
     (2048, 3, 1, 0, 1),      # perc10 with an odd hop (205): 4-byte aligned pair loads
     (512, 3, 1, 0, 1),
+    (1024, 1, 3, 0, 1),      # AbsMean over a non-power-of-two channel count: IEEE division path
+    (1024, 1, 5, 0, 1),
+    (1024, 1, 64, 0, 1),     # the full 64-channel mix of configs[3] on one GPU
+    (1024, 0, 2, 0, 1),      # perc100: no overlap
 ]
 
 
