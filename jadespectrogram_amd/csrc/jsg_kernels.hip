@@ -202,12 +202,10 @@ struct StftKArgs {
 };
 
 // dB = 10*log10(p + 1e-11f) -- reference Spectrogram.cpp:107 with g_minValForLogSpectrogram (:36).
-// v_log_f32 (log2, 1 ulp) times 10*log10(2) split hi/lo; inputs are >= 1e-11, never denormal.
+// v_log_f32 (log2, 1 ulp) times float(10*log10(2)); inputs are >= 1e-11, never denormal.  The constant's rounding
+// (<= 6e-8 relative) stays below half an ulp of the dB value, so no hi/lo split is spent on it.
 __device__ __forceinline__ float to_db(float p) {
-    const float l2 = __builtin_amdgcn_logf(p + 1e-11f);
-    constexpr float kHi = 3.0102999566398120f;                       // float(10*log10(2))
-    constexpr float kLo = (float)(3.010299956639811952137 - (double)kHi);
-    return __builtin_fmaf(l2, kHi, l2 * kLo);
+    return __builtin_amdgcn_logf(p + 1e-11f) * 3.0102999566398120f;
 }
 
 template <int MIXOP>
@@ -582,7 +580,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
 #pragma unroll
                 for (int m = 0; m < P; ++m) acc[m] = acc[m] / a.divisor;
                 accNy = accNy / a.divisor;
-            } else {             // power-of-two channel count: the same division as an exact scaling
+            } else if (a.scale != 1.0f) {   // power-of-two channel count: the same division as an exact scaling
 #pragma unroll
                 for (int m = 0; m < P; ++m) acc[m] *= a.scale;
                 accNy *= a.scale;
