@@ -173,3 +173,21 @@ def test_display_tile_updates_match_full_image(jsg, oracle):
     need_full, nv, pos = d.timerCallbackTile(tile)
     assert need_full and nv == 24
     s.close()
+
+
+def test_colormap_non_finite_values_stay_in_range(jsg, oracle, torch_cuda):
+    """NaN / +-Inf dB values (the reference's int(NaN) is undefined behaviour) must map to a valid palette entry."""
+    torch = torch_cuda
+    v = np.array([[np.nan, np.inf, -np.inf, 1e38, -1e38, 0.0, -0.0, 49.999996]], dtype=np.float32)
+    d_db = torch.from_numpy(v.copy()).cuda()
+    d_lut = torch.from_numpy(jsg.colormap_lut(256, 6)).cuda()
+    d_img = torch.zeros((8, 1), dtype=torch.int32, device="cuda")
+    d_idx = torch.full((8, 1), 77, dtype=torch.uint8, device="cuda")
+    jsg.colormap(d_db, d_lut, -50.0, 50.0, d_argb=d_img, d_index=d_idx)
+    torch.cuda.synchronize()
+    idx = d_idx.cpu().numpy()[::-1, 0]
+    pal = oracle.OracleColorPalette(256, 6); pal.set_value_range(-50.0, 50.0)
+    assert idx[0] == 0                                            # NaN: every comparison false, cvt(NaN) = 0
+    assert (idx[1:] == pal.index(v[0, 1:])).all()                 # infinities and huge values clamp like finite ones
+    lut = jsg.colormap_lut(256, 6)
+    assert (d_img.cpu().numpy()[::-1, 0].view(np.uint32) == (lut[idx].astype(np.int64) | 0xFF000000).astype(np.uint32)).all()

@@ -345,3 +345,20 @@ def test_launches_are_graph_capturable(jsg, oracle, torch_cuda):
     g.replay(); g.replay()
     torch.cuda.synchronize()
     assert torch.equal(ring_g[:, :513], ring_e[:, :513]) and torch.equal(img_g, img_e)
+
+
+@pytest.mark.parametrize("scale", [32768.0, 1e-6])
+def test_amplitude_extremes(jsg, oracle, scale):
+    """PCM-scale and very quiet signals: no overflow, and the 1e-11 floor dominates exactly like in the reference."""
+    n = 1024
+    x = (oracle.synth_audio(1, 4 * n, seed=19) * np.float32(scale)).astype(np.float32)
+    s = jsg.Spectrogram(1)
+    s.setSamplerate(48000.0); s.setFFTSize(n); s.setfeed_percent(1)
+    s.processBlocks(x)
+    mem = np.zeros((s.getMemorySize(), 513), np.float32); s.getMem(mem)
+    win = oracle.window(1, n)
+    ref = oracle.stft_db_reference(x, n, 512, 2, win)
+    pw = mixed_power_f64(oracle, x, n, 512, 2, win, 0)
+    assert_db_close(mem[:8], ref, pw, f"scale {scale}")
+    assert np.isfinite(mem[:8]).all()
+    s.close()
