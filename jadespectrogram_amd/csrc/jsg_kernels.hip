@@ -199,6 +199,7 @@ struct StftKArgs {
     int iters;
     const float2* tab;   // [4][P][64]: window pairs, stage-1 twiddles, stage-2 twiddles, post-pass twiddles
     unsigned long long* stamps;   // development (ABL == 3): 4 s_memtime stamps per wave
+    int xcd_remap;                // 1: XCD-aware block remap (default); 0: identity (development A/B)
 };
 
 // dB = 10*log10(p + 1e-11f) -- reference Spectrogram.cpp:107 with g_minValForLogSpectrogram (:36).
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
     // contiguous range of frames so that the overlapped halves of neighbouring frames hit the same L2.
     const unsigned nblk = gridDim.x, b = blockIdx.x;
     const unsigned q = nblk >> 3, r = nblk & 7, xcd = b & 7;
-    const unsigned lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const unsigned lb = a.xcd_remap ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3) : b;
 
     // ---- task bookkeeping (32-bit, scalar): task t of this launch is frame t; the channel range is fixed ----
     const unsigned task0 = lb * (unsigned)a.iters * C::TPB + slot0;   // first task of this wave (sub 0)
@@ -934,6 +935,8 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
     ka.ring_pos = g->ring_pos;
     ka.tab = plan->d_tab;
     ka.stamps = g_dev_stamps;
+    static const int xcd_remap = getenv("JSG_NO_XCD_REMAP") ? 0 : 1;
+    ka.xcd_remap = xcd_remap;
     ka.per_channel = 0;
     ka.c_begin = 0;
     ka.c_end = g->channels;
