@@ -132,6 +132,12 @@ typedef struct jsg_stft_args {
 } jsg_stft_args;
 int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* args, void* stream);
 
+/* `count` independent launches issued from one call, launch i on streams[i % n_streams] (hipStream_t handles; NULL or
+ * n_streams == 0: the default stream).  For batches that do not depend on each other (distinct input and output
+ * buffers): takes the per-launch FFI cost out of the caller's loop and, with more than one stream, lets the tail of
+ * one launch overlap the ramp-up of the next.  Ordering between the streams is the caller's business. */
+int jsg_stft_db_launch_many(const jsg_plan* plan, const jsg_stft_args* args, int count, void* const* streams, int n_streams);
+
 /* out[i] = 10*log10(power[i]/divisor + 1e-11f), i < count: the tail of the mix (reference Spectrogram.cpp:74,107)
  * for partial sums that were reduced across GPUs (JSG_MIX_SUM).  In place (out == power) is allowed. */
 int jsg_db_from_power_launch(const float* power, float* out, int64_t count, float divisor, void* stream);

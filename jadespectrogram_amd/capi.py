@@ -64,6 +64,7 @@ SIGNATURES = {
     "jsg_plan_destroy": (C.c_int, [_P]),
     "jsg_plan_fft_size": (C.c_int, [_P]),
     "jsg_stft_db_launch": (C.c_int, [_P, C.POINTER(StftArgs), _P]),
+    "jsg_stft_db_launch_many": (C.c_int, [_P, C.POINTER(StftArgs), C.c_int, C.POINTER(_P), C.c_int]),
     "jsg_colormap_launch": (C.c_int, [C.POINTER(ColormapArgs), _P]),
     "jsg_db_from_power_launch": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
     "jsg_create": (C.c_int, [C.POINTER(_P), C.c_int]),

@@ -1023,6 +1023,17 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
     return JSG_OK;
 }
 
+int jsg_stft_db_launch_many(const jsg_plan* plan, const jsg_stft_args* args, int count, void* const* streams, int n_streams) {
+    if (!plan || (!args && count > 0) || count < 0 || n_streams < 0 || (n_streams > 0 && !streams))
+        return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch_many: bad argument");
+    for (int i = 0; i < count; ++i) {
+        void* st = n_streams > 0 ? streams[i % n_streams] : nullptr;
+        const int rc = jsg_stft_db_launch(plan, &args[i], st);
+        if (rc != JSG_OK) return rc;
+    }
+    return JSG_OK;
+}
+
 int jsg_db_from_power_launch(const float* power, float* out, int64_t count, float divisor, void* stream) {
     if (count == 0) return JSG_OK;
     if (!power || !out || count < 0 || !(divisor > 0.f)) return jsg_fail(JSG_ERR_INVALID, "jsg_db_from_power_launch: bad argument");

@@ -362,3 +362,33 @@ def test_amplitude_extremes(jsg, oracle, scale):
     assert_db_close(mem[:8], ref, pw, f"scale {scale}")
     assert np.isfinite(mem[:8]).all()
     s.close()
+
+
+def test_launch_many_on_several_streams_equals_single_launches(jsg, oracle, torch_cuda):
+    """jsg_stft_db_launch_many: independent batches issued from one call over several HIP streams give the same bits
+    as one launch at a time."""
+    import ctypes as C
+    from jadespectrogram_amd import capi
+    from jadespectrogram_amd.spectrogram import _stft_args
+    torch = torch_cuda
+    n, hop, F, B = 1024, 512, 96, 6
+    plan = jsg.Plan(n, oracle.window(1, n))
+    xs = [torch.from_numpy(oracle.synth_audio(1, F * hop + n, seed=40 + b)).cuda() for b in range(B)]
+    ref = [torch.zeros((F, 544), device="cuda") for _ in range(B)]
+    out = [torch.zeros((F, 544), device="cuda") for _ in range(B)]
+    for b in range(B):
+        jsg.stft_db(plan, xs[b], hop, F, ref[b])
+    torch.cuda.synchronize()
+    arr = (capi.StftArgs * B)()
+    for b in range(B):
+        a = _stft_args(plan, xs[b], hop, F, out[b])
+        C.memmove(C.byref(arr, b * C.sizeof(capi.StftArgs)), C.byref(a), C.sizeof(capi.StftArgs))
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    sarr = (C.c_void_p * 3)(*[s.cuda_stream for s in streams])
+    capi.check(capi.lib().jsg_stft_db_launch_many(plan._p, arr, B, sarr, 3))
+    torch.cuda.synchronize()
+    for b in range(B):
+        assert torch.equal(out[b][:, :513], ref[b][:, :513])
+    assert capi.lib().jsg_stft_db_launch_many(plan._p, arr, 0, None, 0) == 0          # empty list is a no-op
+    assert capi.lib().jsg_stft_db_launch_many(plan._p, arr, 2, None, 0) == 0          # default stream
+    torch.cuda.synchronize()
