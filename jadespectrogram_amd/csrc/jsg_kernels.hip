@@ -200,6 +200,7 @@ struct StftKArgs {
     const float2* tab;   // [4][P][64]: window pairs, stage-1 twiddles, stage-2 twiddles, post-pass twiddles
     unsigned long long* stamps;   // development (ABL == 3): 4 s_memtime stamps per wave
     int xcd_remap;                // 1: XCD-aware block remap (default); 0: identity (development A/B)
+    int chunked;                  // 0: grid-stride traversal (default); 1: one contiguous chunk per workgroup
 };
 
 // dB = 10*log10(p + 1e-11f) -- reference Spectrogram.cpp:107 with g_minValForLogSpectrogram (:36).
@@ -271,7 +272,12 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
     const unsigned lb = a.xcd_remap ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3) : b;
 
     // ---- task bookkeeping (32-bit, scalar): task t of this launch is frame t; the channel range is fixed ----
-    const unsigned task0 = lb * (unsigned)a.iters * C::TPB + slot0;   // first task of this wave (sub 0)
+    // Grid-stride traversal: in iteration `it` the workgroups cover one contiguous window of gridDim.x*TPB frames that
+    // sweeps through the stream (neighbouring workgroups touch neighbouring DRAM pages at the same time), instead
+    // of every workgroup streaming through a private region (thousands of concurrent streams: 10-15 % less HBM
+    // bandwidth, see tools/copy_width_probe.py).  JSG_TRAVERSAL=chunk selects the old order (development A/B).
+    const unsigned task_stride = a.chunked ? C::TPB : nblk * C::TPB;
+    const unsigned task0 = (a.chunked ? lb * (unsigned)a.iters * C::TPB : lb * C::TPB) + slot0;   // first task of this wave
     const int c0 = a.per_channel ? (int)blockIdx.y : a.c_begin;
     const int c1 = a.per_channel ? (int)blockIdx.y + 1 : a.c_end;
     const int nc = c1 - c0;
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
     auto frame_src = [&](int s) -> const f2u* {
         const unsigned it = (nc == 1) ? (unsigned)s : (unsigned)s / (unsigned)nc;
         const int c = c0 + (s - (int)it * nc);
-        unsigned t = task0 + it * C::TPB + sub;
+        unsigned t = task0 + it * task_stride + sub;
         if (t >= a.n_frames) t = a.n_frames - 1;   // keep the lanes busy with a duplicate; its stores are masked
         const unsigned j = a.first_frame + t;
         long long start;
@@ -572,7 +578,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
         // ---- last channel of this column: mix epilogue + dB + ring store ----
         const unsigned it = (nc == 1) ? (unsigned)s : (unsigned)s / (unsigned)nc;
         if (s - (int)it * nc == nc - 1) {
-            const unsigned t = task0 + it * C::TPB + sub;
+            const unsigned t = task0 + it * task_stride + sub;
             unsigned col = a.ring_pos + t;                     // n_frames <= ring_w (checked by the launcher)
             if (col >= (unsigned)a.ring_w) col -= a.ring_w;
             float* dst = a.out + (long long)col * a.out_pitch + (a.per_channel ? (long long)c0 * a.out_cpitch : 0ll);
@@ -841,9 +847,29 @@ __global__ __launch_bounds__(256) void dev_copy_kernel(const float4* __restrict_
 
 extern "C" {
 
+// development only: the same copy with the STFT kernel's access widths (8-byte loads, 4-byte nt stores)
+__global__ __launch_bounds__(256) void dev_copy_narrow_kernel(const float2* __restrict__ src, float* __restrict__ dst, long long n2) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n2; i += 4 * stride) {
+        const float2 a = src[i], b = src[i + stride], c = src[i + 2 * stride], e = src[i + 3 * stride];
+        float* d0 = dst + 2 * (i - (i % blockDim.x));   // keep each store instruction 256 B contiguous per wave
+        const long long l = i % blockDim.x;
+        __builtin_nontemporal_store(a.x, &d0[l]); __builtin_nontemporal_store(a.y, &d0[l + blockDim.x]);
+        float* d1 = d0 + 2 * stride; __builtin_nontemporal_store(b.x, &d1[l]); __builtin_nontemporal_store(b.y, &d1[l + blockDim.x]);
+        float* d2 = d1 + 2 * stride; __builtin_nontemporal_store(c.x, &d2[l]); __builtin_nontemporal_store(c.y, &d2[l + blockDim.x]);
+        float* d3 = d2 + 2 * stride; __builtin_nontemporal_store(e.x, &d3[l]); __builtin_nontemporal_store(e.y, &d3[l + blockDim.x]);
+    }
+}
+
 // development only (not part of include/jsg.h): streaming copy microbenchmark (tools/copy_floor.py)
 int jsg_dev_copy_launch(const void* src, void* dst, long long bytes, int blocks, int nt, void* stream) {
     const long long n4 = bytes / 16;
+    if (nt == 2) {
+        hipLaunchKernelGGL(dev_copy_narrow_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           static_cast<const float2*>(src), static_cast<float*>(dst), bytes / 8);
+        return hipGetLastError() == hipSuccess ? 0 : -4;
+    }
     if (nt) hipLaunchKernelGGL(dev_copy_kernel<true>, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                                static_cast<const float4*>(src), static_cast<float4*>(dst), n4);
     else hipLaunchKernelGGL(dev_copy_kernel<false>, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
@@ -937,6 +963,8 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
     ka.stamps = g_dev_stamps;
     static const int xcd_remap = getenv("JSG_NO_XCD_REMAP") ? 0 : 1;
     ka.xcd_remap = xcd_remap;
+    static const int chunked = [] { const char* e = getenv("JSG_TRAVERSAL"); return (e && e[0] == 'c') ? 1 : 0; }();
+    ka.chunked = chunked;
     ka.per_channel = 0;
     ka.c_begin = 0;
     ka.c_end = g->channels;
