@@ -178,6 +178,10 @@ using Cfg1024N = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 0, false
 using Cfg1024U = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 0, true, false>;
 using Cfg1024M = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 1, true>;
 using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 1, 1>;   // (12-wave workgroups measured slower: 303 vs 410 Mframes/s)
+// development variants of the 2048-point plan (JSG_2048_VARIANT)
+using Cfg2048T0 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 0, 1>;          // tables from global memory (L1/L2), no LDS copy
+using Cfg2048W8 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 8, 1, 2>;          // 8-wave workgroups
+using Cfg2048T0W8 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 8, 0, 2>;
 using Cfg4096 = Cfg<4096, 16, 8, 16, 128, 144, 1, 272, 17, 8, 1, 1, 0, 0, 1>;    // two wavefronts per frame
 using Cfg8192 = Cfg<8192, 16, 16, 16, 256, 272, 1, 272, 17, 8, 0, 1, 0, 0, 1>;   // four wavefronts per frame
 
@@ -1004,7 +1008,11 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
             tpb = Cfg1024::TPB;
             break;
         }
-        case 2048: tpb = Cfg2048::TPB; break;
+        case 2048: {
+            const char* e = getenv("JSG_2048_VARIANT");
+            tpb = (e && (e[0] == 'W' || e[0] == 'X')) ? Cfg2048W8::TPB : Cfg2048::TPB;
+            break;
+        }
         case 4096: tpb = Cfg4096::TPB; break;
         case 8192: tpb = Cfg8192::TPB; break;
     }
@@ -1043,7 +1051,16 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
             }
             break;
         }
-        case 2048: err = launch_stft<Cfg2048>(ka, mixop, grid, s); break;
+        case 2048: {
+            static const int v2048 = [] { const char* e = getenv("JSG_2048_VARIANT"); return e ? e[0] : '-'; }();
+            switch (v2048) {
+                case 'T': err = launch_stft<Cfg2048T0>(ka, mixop, grid, s); break;
+                case 'W': err = launch_stft<Cfg2048W8>(ka, mixop, grid, s); break;
+                case 'X': err = launch_stft<Cfg2048T0W8>(ka, mixop, grid, s); break;
+                default: err = launch_stft<Cfg2048>(ka, mixop, grid, s); break;
+            }
+            break;
+        }
         case 4096: err = launch_stft<Cfg4096>(ka, mixop, grid, s); break;
         case 8192: err = launch_stft<Cfg8192>(ka, mixop, grid, s); break;
     }
