@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--nbuf", type=int, default=24, help="distinct batches rotated through (24 x 16.8 MB > 256 MiB)")
-    ap.add_argument("--streams", type=int, default=4, help="HIP streams the independent launches are spread over")
+    ap.add_argument("--streams", type=int, default=8, help="HIP streams the independent launches are spread over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -32,7 +32,7 @@ for i in range(K):
     a = _stft_args(plan, d_in[i % nbuf], hop, frames, d_out[i % nbuf], feedblocks=2)
     C.memmove(C.byref(arr, i * C.sizeof(capi.StftArgs)), C.byref(a), C.sizeof(capi.StftArgs))
 lib = capi.lib()
-for S in (1, 4):
+for S in (8,):
     streams = [torch.cuda.Stream() for _ in range(S)]
     sarr = (C.c_void_p * S)(*[s.cuda_stream for s in streams])
     lib.jsg_stft_db_launch_many(plan._p, arr, 200, sarr, S); torch.cuda.synchronize()
