@@ -147,3 +147,27 @@ def test_c5_stereo_96k_4096_with_colormap(jsg, oracle, torch_cuda):
     xs = (np.arange(F) + (F - pos)) % F
     ref_idx = np.zeros((H, F), np.uint8); ref_idx[::-1, :][:, xs] = pal.index(db).T.astype(np.uint8)
     assert (d_idx.cpu().numpy() == ref_idx).all()
+
+
+@pytest.mark.parametrize("n,F", [(4096, 9000), (8192, 5000), (2048, 20000), (512, 40000)])
+def test_persistent_loop_of_every_plan(jsg, oracle, torch_cuda, n, F):
+    """Launches large enough that every workgroup loops over several frames (iters > 1), incl. the plans whose frames
+    span 2 / 4 wavefronts (workgroup barriers inside the loop): spot checks + batching invariance."""
+    torch = torch_cuda
+    hop, C = 256, 2
+    win = oracle.window(oracle.WIN_HANN, n)
+    plan = jsg.Plan(n, win)
+    d_in = _stream(torch, C, (F - 1) * hop + n, seed=n)
+    H = n // 2 + 1
+    pitch = (H + 31) // 32 * 32
+    d_a = torch.empty((F, pitch), device="cuda")
+    d_b = torch.empty((F, pitch), device="cuda")
+    fb = n // hop
+    jsg.stft_db(plan, d_in, hop, F, d_a, feedblocks=fb)
+    half = F // 2 + 3
+    jsg.stft_db(plan, d_in, hop, half, d_b, feedblocks=fb)
+    jsg.stft_db(plan, d_in, hop, F - half, d_b, feedblocks=fb, first_frame=half, ring_pos=half)
+    torch.cuda.synchronize()
+    assert torch.equal(d_a[:, :H], d_b[:, :H])
+    frames = sorted(np.random.default_rng(n).choice(F, 6, replace=False).tolist()) + [0, F - 1]
+    _spot_check(oracle, d_in, d_a[frames][:, :H].cpu().numpy(), n, hop, win, frames)
