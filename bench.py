@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--nbuf", type=int, default=24, help="distinct batches rotated through (24 x 16.8 MB > 256 MiB)")
     ap.add_argument("--streams", type=int, default=8, help="HIP streams the independent launches are spread over")
+    ap.add_argument("--blocks-per-cu", type=int, default=1, help="workgroups per CU of each launch in the concurrent pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -135,17 +136,21 @@ def main():
     while args.nbuf % n_streams:        # a batch must always land on the same stream (its ring is rewritten in order)
         n_streams -= 1
     total = max(args.steps, args.warmup)
+    # concurrent pass: one workgroup per CU, two frames per wavefront with prefetch (fewer, longer-lived workgroups
+    # overlap better across launches); in-order pass: the default geometry (best for one launch alone)
     arr = (capi.StftArgs * total)()
+    arr_inorder = (capi.StftArgs * total)()
     for i in range(total):
-        a_i = _stft_args(plan, d_in[i % args.nbuf], HOP, FRAMES, d_out[i % args.nbuf], feedblocks=2)
-        ctypes.memmove(ctypes.byref(arr, i * ctypes.sizeof(capi.StftArgs)), ctypes.byref(a_i), ctypes.sizeof(capi.StftArgs))
+        for dst_arr, bpc in ((arr, args.blocks_per_cu if n_streams > 1 else 0), (arr_inorder, 0)):
+            a_i = _stft_args(plan, d_in[i % args.nbuf], HOP, FRAMES, d_out[i % args.nbuf], feedblocks=2, blocks_per_cu=bpc)
+            ctypes.memmove(ctypes.byref(dst_arr, i * ctypes.sizeof(capi.StftArgs)), ctypes.byref(a_i), ctypes.sizeof(capi.StftArgs))
     streams = [torch.cuda.Stream() for _ in range(n_streams)]
     sarr = (ctypes.c_void_p * n_streams)(*[st.cuda_stream for st in streams])
     one = torch.cuda.Stream()
     one_arr = (ctypes.c_void_p * 1)(one.cuda_stream)
 
-    def run(count, handles, n):
-        capi.check(lib.jsg_stft_db_launch_many(plan._p, arr, count, handles, n))
+    def run(count, handles, n, which=None):
+        capi.check(lib.jsg_stft_db_launch_many(plan._p, which if which is not None else arr, count, handles, n))
 
     def barrier():
         if dist is not None:
@@ -162,11 +167,11 @@ def main():
     wall = t1 - t0
 
     # in-order pass for the per-kernel roofline (not part of `value`)
-    run(min(args.warmup, 50), one_arr, 1)
+    run(min(args.warmup, 50), one_arr, 1, arr_inorder)
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record(one)
-    run(args.steps, one_arr, 1)
+    run(args.steps, one_arr, 1, arr_inorder)
     ev1.record(one)
     torch.cuda.synchronize()
     ev_ms = ev0.elapsed_time(ev1)                       # events on the stream the kernel runs on

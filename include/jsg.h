@@ -128,7 +128,9 @@ typedef struct jsg_stft_args {
     int32_t ring_width;
     int32_t ring_pos;
     int32_t linear_out;      /* 0: dB = 10*log10(p + 1e-11f) (the reference's column); 1: mixed linear power p */
-    int32_t reserved;
+    int32_t blocks_per_cu;   /* 0: default (up to 8 workgroups per CU, the rest of the frames is looped over); smaller values make
+                                fewer, longer-lived workgroups that prefetch their next frame -- better when several
+                                launches run concurrently, worse for one launch alone */
 } jsg_stft_args;
 int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* args, void* stream);
 

@@ -1027,7 +1027,8 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
         const int v = e ? atoi(e) : 0;
         return v > 0 ? v : 8;
     }();
-    long long max_blocks = 256ll * blocks_per_cu / ny;     // resident workgroups; the rest is looped over
+    const int bpc = g->blocks_per_cu > 0 ? g->blocks_per_cu : blocks_per_cu;
+    long long max_blocks = 256ll * bpc / ny;     // resident workgroups; the rest is looped over
     if (max_blocks < 64) max_blocks = 64;
     const int nblk = int(want < max_blocks ? want : max_blocks);
     ka.iters = int((g->n_frames + (long long)nblk * tpb - 1) / ((long long)nblk * tpb));

@@ -261,19 +261,20 @@ class StftLaunch:
 
 
 def stft_db(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: int | None = None, mix_mode: int = 0,
-            first_frame: int = 0, ring_pos: int = 0, linear_out: bool = False, stream: int | None = None):
+            first_frame: int = 0, ring_pos: int = 0, linear_out: bool = False, blocks_per_cu: int = 0,
+            stream: int | None = None):
     """Enqueue one fused STFT->dB launch.  d_in: torch CUDA float32 [C][samples]; d_out: [W][pitch] (or
     [C][W][pitch] with mix_mode PER_CHANNEL).  Frame j starts at sample (j//feedblocks)*n + (j%feedblocks)*hop."""
     import torch
     a = _stft_args(plan, d_in, hop, n_frames, d_out, feedblocks=feedblocks, mix_mode=mix_mode, first_frame=first_frame,
-                   ring_pos=ring_pos, linear_out=linear_out)
+                   ring_pos=ring_pos, linear_out=linear_out, blocks_per_cu=blocks_per_cu)
     if stream is None:
         stream = torch.cuda.current_stream(d_in.device).cuda_stream
     check(lib().jsg_stft_db_launch(plan._p, C.byref(a), C.c_void_p(stream)))
 
 
 def _stft_args(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: int | None = None, mix_mode: int = 0,
-               first_frame: int = 0, ring_pos: int = 0, linear_out: bool = False):
+               first_frame: int = 0, ring_pos: int = 0, linear_out: bool = False, blocks_per_cu: int = 0):
     import torch
     assert d_in.is_cuda and d_in.dtype == torch.float32 and d_in.dim() == 2 and d_in.stride(1) == 1
     assert d_out.is_cuda and d_out.dtype == torch.float32 and d_out.stride(-1) == 1
@@ -292,6 +293,7 @@ def _stft_args(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: 
     a.ring_width = d_out.shape[-2]
     a.ring_pos = ring_pos
     a.linear_out = int(bool(linear_out))
+    a.blocks_per_cu = int(blocks_per_cu)
     return a
 
 

@@ -66,8 +66,11 @@ def test_c2_mono_1024_4096_frames_per_launch(jsg, oracle, torch_cuda):
     d_two = torch.empty((F, pitch), device="cuda")
     jsg.stft_db(plan, d_in, hop, 2048, d_two)
     jsg.stft_db(plan, d_in, hop, 2048, d_two, first_frame=2048, ring_pos=2048)
+    d_hint = torch.empty((F, pitch), device="cuda")
+    jsg.stft_db(plan, d_in, hop, F, d_hint, blocks_per_cu=1)     # persistent-style grid: two frames per wavefront
     torch.cuda.synchronize()
     assert torch.equal(d_db[:, :H], d_two[:, :H])
+    assert torch.equal(d_db[:, :H], d_hint[:, :H])
     frames = sorted(np.random.default_rng(0).choice(F, 64, replace=False).tolist())
     _parseval_check(torch, d_in, d_pw, n, hop, win, frames)
     _spot_check(oracle, d_in, d_db[frames][:, :H].cpu().numpy(), n, hop, win, frames)
