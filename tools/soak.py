@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""DEV TOOL: soak / determinism check.  Every plan is launched thousands of times on several concurrent HIP streams
+(different timing, co-resident workgroups of different launches); each output must stay bit-identical to the first."""
+import ctypes as C, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import jadespectrogram_amd as jsg
+from jadespectrogram_amd import capi
+from jadespectrogram_amd.spectrogram import _stft_args
+lib = capi.lib()
+for n, frames, ch in ((512, 3001, 1), (1024, 4096, 1), (1024, 1000, 3), (2048, 2049, 2), (4096, 1025, 1), (8192, 513, 2)):
+    hop = n // 4
+    H = n // 2 + 1; pitch = (H + 31) // 32 * 32
+    plan = jsg.Plan(n, jsg.window(2, n))
+    S, B = 6, 12
+    xs = [torch.rand((ch, (frames - 1) * hop + n), device="cuda") * 2 - 1 for _ in range(B)]
+    ref = [torch.empty((frames, pitch), device="cuda") for _ in range(B)]
+    out = [torch.empty((frames, pitch), device="cuda") for _ in range(B)]
+    for b in range(B):
+        jsg.stft_db(plan, xs[b], hop, frames, ref[b], feedblocks=4)
+    torch.cuda.synchronize()
+    reps = 150
+    arr = (capi.StftArgs * (B * reps))()
+    for i in range(B * reps):
+        a = _stft_args(plan, xs[i % B], hop, frames, out[i % B], feedblocks=4, blocks_per_cu=(i // B) % 3)
+        C.memmove(C.byref(arr, i * C.sizeof(capi.StftArgs)), C.byref(a), C.sizeof(capi.StftArgs))
+    streams = [torch.cuda.Stream() for _ in range(S)]
+    sarr = (C.c_void_p * S)(*[s.cuda_stream for s in streams])
+    t0 = time.perf_counter()
+    bad = 0
+    for r in range(6):
+        capi.check(lib.jsg_stft_db_launch_many(plan._p, arr, B * reps, sarr, S))
+        torch.cuda.synchronize()
+        for b in range(B):
+            if not torch.equal(out[b][:, :H], ref[b][:, :H]):
+                bad += 1
+            out[b].zero_()
+    print(json.dumps(dict(n=n, frames=frames, channels=ch, launches=6 * B * reps, mismatching_buffers=bad,
+                          seconds=round(time.perf_counter() - t0, 2))), flush=True)
+    assert bad == 0
+print("soak ok")
