@@ -81,8 +81,8 @@ def cpu_baseline(seconds_budget: float = 12.0, check=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--nbuf", type=int, default=24, help="distinct batches rotated through (24 x 16.8 MB > 256 MiB)")
     ap.add_argument("--streams", type=int, default=8, help="HIP streams the independent launches are spread over")
     ap.add_argument("--blocks-per-cu", type=int, default=1, help="workgroups per CU of each launch in the concurrent pass")
