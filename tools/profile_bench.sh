@@ -10,7 +10,7 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # --streams 1: every dispatch runs alone, so rocprofv3's per-dispatch duration is the per-kernel number that
 # bench.py's `roofline` (its in-order pass) reports; the default multi-stream timed region overlaps dispatches
-CMD="python3 $GRAFT_REPO_ROOT/bench.py --streams 1 --steps 500 --warmup 50 --no-cpu-baseline"
+CMD="python3 $GRAFT_REPO_ROOT/bench.py --streams 1 --steps 5000 --warmup 500 --no-cpu-baseline"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1 || echo "stats pass failed"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/fetch.log 2>&1 || echo "fetch pass failed"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/write.log 2>&1 || echo "write pass failed"

@@ -5,7 +5,7 @@ out_dir, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(os.environ.get("GRAFT_REPO_ROOT", root), "gpurun_out", f"profiles_{tag}")
 os.makedirs(dst, exist_ok=True)
-res = {"tag": tag, "command": "python3 bench.py --streams 1 --steps 500 --warmup 50 --no-cpu-baseline"}
+res = {"tag": tag, "command": "python3 bench.py --streams 1 --steps 5000 --warmup 500 --no-cpu-baseline"}
 # 1. kernel stats
 for f in glob.glob(os.path.join(out_dir, "stats", "**", "*kernel_stats.csv"), recursive=True):
     rows = list(csv.DictReader(open(f)))
