@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <new>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -221,7 +222,8 @@ template <int MIXOP>
 __device__ __forceinline__ float mix_combine(float acc, float pw) {
     if constexpr (MIXOP == 0) return acc + pw;                  // AbsMean / Sum: m_powerfinal += m_power[cc]  (:72)
     else if constexpr (MIXOP == 1) return pw > acc ? pw : acc;  // Max (:81)
-    else return pw < acc ? pw : acc;                            // Min (:89)
+    else if constexpr (MIXOP == 2) return pw < acc ? pw : acc;  // Min (:89)
+    else return pw;                                             // one channel per column: 0 + pw == pw exactly
 }
 
 // Cross-lane helpers for the register-only exchange (gfx950: v_permlane32_swap / v_permlane16_swap / DPP row_ror).
@@ -242,7 +244,11 @@ __device__ __forceinline__ void swap_lane8(float& a, float& b, bool hi) {   // a
     b = hi ? b : recv;
 }
 
-// MIXOP: 0 sum (AbsMean, Left, Right, per-channel), 1 max, 2 min
+// MIXOP: 0 sum over a channel range (AbsMean, Sum), 1 max, 2 min, 3 exactly one channel per column (mono, Left, Right,
+// per-channel): the channel bookkeeping folds away and every iteration ends in the store epilogue, which makes the
+// number of vector-memory instructions per iteration a compile-time fact -- the s_waitcnt the compiler places in
+// front of the next frame's data then counts past the (younger) column stores instead of waiting for their
+// write acknowledgements.
 template <class C, int MIXOP>
 __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
     // the values the first loads depend on come first: with -amdgpu-kernarg-preload-count they arrive in SGPRs
@@ -287,7 +293,8 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
     const unsigned task0 = (a.chunked ? lb * (unsigned)a.iters * C::TPB : lb * C::TPB) + slot0;   // first task of this wave
     const int c0 = a.per_channel ? (int)blockIdx.y : a.c_begin;
     const int c1 = a.per_channel ? (int)blockIdx.y + 1 : a.c_end;
-    const int nc = c1 - c0;
+    constexpr bool ONE = MIXOP == 3;
+    const int nc = ONE ? 1 : c1 - c0;
     const int n_fft = a.iters * nc;   // FFTs this wave performs, s = it*nc + (c - c0)
     auto frame_src = [&](int s) -> const f2u* {
         const unsigned it = (nc == 1) ? (unsigned)s : (unsigned)s / (unsigned)nc;
@@ -392,7 +399,10 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
 
     // One FFT of the sequence: consumes `raw` (loaded two FFTs ago), re-issues it for FFT s+2, transforms,
     // accumulates |X|^2 into acc, and after the last channel of a column runs the mix epilogue + ring store.
-    auto process = [&](auto& raw, int s) {
+    // `last_tag` (std::true_type): the peeled final FFT of the wave, which prefetches nothing.  Peeling keeps the
+    // steady-state loop free of the "did the prefetch happen" merge (16 register moves per FFT and a full vmcnt(0)).
+    auto process = [&](auto& raw, int s, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
         // ---- window multiply ----
         float2 x[P];
         if constexpr (C::ABL == 2) {
@@ -413,7 +423,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (s == 0) st1 = __builtin_readcyclecounter();
         }
-        if (C::ABL != 2 && C::PF > 0 && s + C::PF < n_fft) {
+        if (C::ABL != 2 && C::PF > 0 && !LAST && (C::PF == 1 || s + C::PF < n_fft)) {
             const f2u* src = frame_src(s + C::PF);
 #pragma unroll
             for (int m = 0; m < P; ++m) {
@@ -533,8 +543,18 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
                 acc[rho] = mix_combine<MIXOP>(acc[rho], ax * ax + ay * ay);
                 acc[P / 2 + rho] = mix_combine<MIXOP>(acc[P / 2 + rho], bx * bx + by * by);
             }
-            {   // bin M/2 (meaningful in lane 0 only): the window carries 1/2, so |X|^2 = 4 |Z'|^2
-                const float2 z = x[reg_of(P / 2)];
+            {   // bin M/2 (held by the frame's lane 0): the window carries 1/2, so |X|^2 = 4 |Z'|^2.  For single-wave
+                // frames the value is broadcast so that every lane can take part in an unmasked store below.
+                float2 z = x[reg_of(P / 2)];
+                if constexpr (L == 64) {
+                    z.x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(z.x)));
+                    z.y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(z.y)));
+                } else if constexpr (L == 32) {
+                    const int ax = __builtin_amdgcn_readlane(__float_as_int(z.x), 0), bx = __builtin_amdgcn_readlane(__float_as_int(z.x), 32);
+                    const int ay = __builtin_amdgcn_readlane(__float_as_int(z.y), 0), by = __builtin_amdgcn_readlane(__float_as_int(z.y), 32);
+                    z.x = __int_as_float(sub ? bx : ax);
+                    z.y = __int_as_float(sub ? by : ay);
+                }
                 accNy = mix_combine<MIXOP>(accNy, 4.0f * (z.x * z.x + z.y * z.y));
             }
         } else {
@@ -584,12 +604,18 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
 
         // ---- last channel of this column: mix epilogue + dB + ring store ----
         const unsigned it = (nc == 1) ? (unsigned)s : (unsigned)s / (unsigned)nc;
-        if (s - (int)it * nc == nc - 1) {
-            const unsigned t = task0 + it * task_stride + sub;
+        if (ONE || s - (int)it * nc == nc - 1) {
+            // Tasks past the end of the launch were given frame n_frames-1 again (frame_src): they hold the same
+            // bits as that frame's own wave and store them to the same column, so the stores need no mask.
+            unsigned t = task0 + it * task_stride + sub;
+            if (t >= a.n_frames) t = a.n_frames - 1;
             unsigned col = a.ring_pos + t;                     // n_frames <= ring_w (checked by the launcher)
             if (col >= (unsigned)a.ring_w) col -= a.ring_w;
             float* dst = a.out + (long long)col * a.out_pitch + (a.per_channel ? (long long)c0 * a.out_cpitch : 0ll);
             if constexpr (C::ABL == 3) { if (s == 0) st2 = __builtin_readcyclecounter(); }
+            if constexpr (ONE) {
+                // one channel: the launcher selects this instantiation only when the mix scale is exactly 1
+            } else
             if (a.exact_div) {   // m_powerfinal[kk] /= m_channels (Spectrogram.cpp:74), IEEE division
 #pragma unroll
                 for (int m = 0; m < P; ++m) acc[m] = acc[m] / a.divisor;
@@ -607,7 +633,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
             if constexpr (C::ABLX == 13 || C::ABLX == 14) {
                 // ablation: the same bytes as two 16-byte stores per lane (results meaningless)
                 typedef float v4f __attribute__((ext_vector_type(4)));
-                if (t < a.n_frames) {
+                {
                     v4f* d4 = reinterpret_cast<v4f*>(dst);
                     v4f v0 = {acc[0], acc[1], acc[2], acc[3]}, v1 = {acc[4], acc[5], acc[6], acc[7]};
                     __builtin_nontemporal_store(v0, &d4[ll]);
@@ -615,7 +641,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
                     if (ll == 0) __builtin_nontemporal_store(accNy, &dst[M]);
                 }
             } else if constexpr (C::PAIR) {
-                if (C::ABL == 2 ? (acc[0] == 12345.678f) : (t < a.n_frames)) {
+                if (C::ABL == 2 ? (acc[0] == 12345.678f) : true) {
 #pragma unroll
                     for (int rho = 0; rho < P / 2; ++rho) {
                         if constexpr (C::NT) {
@@ -626,13 +652,13 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
                             dst[M - (ll + L * rho)] = acc[P / 2 + rho];
                         }
                     }
-                    if (ll == 0) {
+                    if (L <= 64 || ll == 0) {   // L <= 64: accNy is uniform over the frame's lanes
                         if constexpr (C::NT) __builtin_nontemporal_store(accNy, &dst[M / 2]);
                         else dst[M / 2] = accNy;
                     }
                 }
             } else
-            if (C::ABL == 2 ? (acc[0] == 12345.678f) : (t < a.n_frames)) {
+            if (C::ABL == 2 ? (acc[0] == 12345.678f) : true) {
 #pragma unroll
                 for (int w = 0; w < U3; ++w) {
 #pragma unroll
@@ -654,11 +680,16 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
 
     if constexpr (C::PF == 2) {
         for (int s = 0; s < n_fft; s += 2) {
-            process(rawA, s);
-            if (s + 1 < n_fft) process(rawB, s + 1);
+            process(rawA, s, std::false_type{});
+            if (s + 1 < n_fft) process(rawB, s + 1, std::false_type{});
+        }
+    } else if constexpr (C::PF == 1) {
+        if (n_fft > 0) {
+            for (int s = 0; s + 1 < n_fft; ++s) process(rawA, s, std::false_type{});
+            process(rawA, n_fft - 1, std::true_type{});
         }
     } else {
-        for (int s = 0; s < n_fft; ++s) process(rawA, s);
+        for (int s = 0; s < n_fft; ++s) process(rawA, s, std::true_type{});
     }
     if constexpr (C::ABL == 3) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -815,6 +846,7 @@ static hipError_t launch_stft(const StftKArgs& ka, int mixop, dim3 grid, hipStre
     switch (mixop) {
         case 1: return launch_stft_mix<C, 1>(ka, grid, s);
         case 2: return launch_stft_mix<C, 2>(ka, grid, s);
+        case 3: return launch_stft_mix<C, 3>(ka, grid, s);
         default: return launch_stft_mix<C, 0>(ka, grid, s);
     }
 }
@@ -1002,6 +1034,8 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
         default: return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: unknown mix mode");
     }
     ka.linear = g->linear_out ? 1 : 0;
+    // one channel per column and nothing to scale: the specialised instantiation (see stft_db_kernel)
+    if (mixop == 0 && (ka.per_channel || ka.c_end - ka.c_begin == 1) && ka.scale == 1.0f && !ka.exact_div) mixop = 3;
     int tpb = 0;
     switch (plan->n) {
         case 512: tpb = Cfg512::TPB; break;
