@@ -5,13 +5,15 @@ ARCH  ?= gfx950
 SRC   := jadespectrogram_amd/csrc
 OUT   := jadespectrogram_amd/libjsg.so
 OBJ   := jadespectrogram_amd/build
+# make DEV=1: also compile the development variants of the kernels (tools/sweep_variants.sh, tools/stamps.py)
+DEVFLAG := $(if $(filter 1,$(DEV)),-DJSG_DEV_VARIANTS,)
 
 .PHONY: lib oracle test-cpp clean
 lib: $(OUT)
 
 $(OBJ)/jsg_kernels.o: $(SRC)/jsg_kernels.hip $(SRC)/jsg_internal.h include/jsg.h
 	@mkdir -p $(OBJ)
-	$(HIPCC) -std=c++17 -O3 -fPIC -Iinclude --offload-arch=$(ARCH) -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=16 -c $< -o $@
+	$(HIPCC) -std=c++17 -O3 -fPIC -Iinclude --offload-arch=$(ARCH) -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=16 $(DEVFLAG) -c $< -o $@
 
 $(OBJ)/%.o: $(SRC)/%.cpp $(SRC)/jsg_internal.h $(SRC)/jsg_colormap_tables.inc include/jsg.h
 	@mkdir -p $(OBJ)

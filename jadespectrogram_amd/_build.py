@@ -36,6 +36,13 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    # JSG_DEV_VARIANTS=1: also compile the development variants of the kernels (tools/sweep_variants.sh, stamps.py ...);
+    # the product build holds the default plans only
+    dev = os.environ.get("JSG_DEV_VARIANTS", "") not in ("", "0")
+    flavour_file = os.path.join(objdir, "flavour")
+    flavour = "dev" if dev else "product"
+    if not os.path.exists(flavour_file) or open(flavour_file).read().strip() != flavour:
+        force = True
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
@@ -48,6 +55,8 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
                 # is gained over two scalar ops, while the packing forces ~140 register moves per FFT
                 # -amdgpu-kernarg-preload-count: the leading scalar kernel arguments are delivered in SGPRs
                 cmd += [f"--offload-arch={ARCH}", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
+                if dev:
+                    cmd.append("-DJSG_DEV_VARIANTS")
             else:
                 # host translation units: keep float arithmetic exactly as written (bit parity with the reference)
                 cmd += ["-ffp-contract=off", "-D__HIP_PLATFORM_AMD__"]
@@ -59,6 +68,8 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+    with open(flavour_file, "w") as f:
+        f.write(flavour + "\n")
     return LIB
 
 

@@ -168,7 +168,9 @@ using Cfg512 = Cfg<512, 8, 8, 4, 32, 36, 4, 33, 1, 8, 1, 2, 0, 0, 1>;
 // default 1024-point plan: both exchanges through LDS, prefetch depth 1, 8 waves per workgroup (fastest of the
 // measured variants, DESIGN.md "Kernel variants")
 using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1>;
-// development variants of the 1024-point plan (selected with JSG_1024_VARIANT, see tools/sweep_variants.sh)
+#ifdef JSG_DEV_VARIANTS
+// development variants of the 1024-point plan (selected with JSG_1024_VARIANT, see tools/sweep_variants.sh); compiled
+// only into development builds (JSG_DEV_VARIANTS=1 python -m jadespectrogram_amd._build)
 using Cfg1024B = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 0, 2>;
 using Cfg1024D = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 1, 1>;
 using Cfg1024G = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 1>;
@@ -181,11 +183,12 @@ using Cfg1024S = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 3>;
 using Cfg1024N = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 0, false>;
 using Cfg1024U = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 0, true, false>;
 using Cfg1024M = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 1, true>;
-using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 1, 1>;   // (12-wave workgroups measured slower: 303 vs 410 Mframes/s)
 // development variants of the 2048-point plan (JSG_2048_VARIANT)
 using Cfg2048T0 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 0, 1>;          // tables from global memory (L1/L2), no LDS copy
 using Cfg2048W8 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 8, 1, 2>;          // 8-wave workgroups
 using Cfg2048T0W8 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 8, 0, 2>;
+#endif
+using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 1, 1>;   // (12-wave workgroups measured slower: 303 vs 410 Mframes/s)
 using Cfg4096 = Cfg<4096, 16, 8, 16, 128, 144, 1, 272, 17, 8, 1, 1, 0, 0, 1>;    // two wavefronts per frame
 using Cfg8192 = Cfg<8192, 16, 16, 16, 256, 272, 1, 272, 17, 8, 0, 1, 0, 0, 1>;   // four wavefronts per frame
 
@@ -1039,20 +1042,20 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
     int tpb = 0;
     switch (plan->n) {
         case 512: tpb = Cfg512::TPB; break;
-        case 1024: {
-            const char* e = getenv("JSG_1024_VARIANT");
-            (void)e;
-            tpb = Cfg1024::TPB;
-            break;
-        }
-        case 2048: {
-            const char* e = getenv("JSG_2048_VARIANT");
-            tpb = (e && (e[0] == 'W' || e[0] == 'X')) ? Cfg2048W8::TPB : Cfg2048::TPB;
-            break;
-        }
+        case 1024: tpb = Cfg1024::TPB; break;
+        case 2048: tpb = Cfg2048::TPB; break;
         case 4096: tpb = Cfg4096::TPB; break;
         case 8192: tpb = Cfg8192::TPB; break;
     }
+    static const int v1024 = [] { const char* e = getenv("JSG_1024_VARIANT"); return e ? e[0] : '-'; }();
+    static const int v2048 = [] { const char* e = getenv("JSG_2048_VARIANT"); return e ? e[0] : '-'; }();
+#ifdef JSG_DEV_VARIANTS
+    if (plan->n == 2048 && (v2048 == 'W' || v2048 == 'X')) tpb = Cfg2048W8::TPB;
+#else
+    if (v1024 != '-' || v2048 != '-')
+        return jsg_fail(JSG_ERR_UNSUPPORTED, "JSG_1024_VARIANT / JSG_2048_VARIANT need a development build of libjsg.so "
+                                             "(JSG_DEV_VARIANTS=1 python -m jadespectrogram_amd._build)");
+#endif
     const long long want = (g->n_frames + tpb - 1) / tpb;
     const int ny = ka.per_channel ? g->channels : 1;
     if (ny > 65535) return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_db_launch: more than 65535 channels in per-channel mode");
@@ -1072,8 +1075,8 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
     switch (plan->n) {
         case 512: err = launch_stft<Cfg512>(ka, mixop, grid, s); break;
         case 1024: {
-            static const int variant = [] { const char* e = getenv("JSG_1024_VARIANT"); return e ? e[0] : '-'; }();
-            switch (variant) {
+            switch (v1024) {
+#ifdef JSG_DEV_VARIANTS
                 case 'B': err = launch_stft<Cfg1024B>(ka, mixop, grid, s); break;
                 case 'D': err = launch_stft<Cfg1024D>(ka, mixop, grid, s); break;
                 case 'G': err = launch_stft<Cfg1024G>(ka, mixop, grid, s); break;
@@ -1085,16 +1088,18 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
                 case 'S': err = launch_stft<Cfg1024S>(ka, mixop, grid, s); break;
                 case 'N': err = launch_stft<Cfg1024N>(ka, mixop, grid, s); break;
                 case 'M': err = launch_stft<Cfg1024M>(ka, mixop, grid, s); break;
+#endif
                 default: err = launch_stft<Cfg1024>(ka, mixop, grid, s); break;
             }
             break;
         }
         case 2048: {
-            static const int v2048 = [] { const char* e = getenv("JSG_2048_VARIANT"); return e ? e[0] : '-'; }();
             switch (v2048) {
+#ifdef JSG_DEV_VARIANTS
                 case 'T': err = launch_stft<Cfg2048T0>(ka, mixop, grid, s); break;
                 case 'W': err = launch_stft<Cfg2048W8>(ka, mixop, grid, s); break;
                 case 'X': err = launch_stft<Cfg2048T0W8>(ka, mixop, grid, s); break;
+#endif
                 default: err = launch_stft<Cfg2048>(ka, mixop, grid, s); break;
             }
             break;
