@@ -34,71 +34,106 @@
 namespace jsg {
 
 // ------------------------------------------------------------------------------------------------------------
-// small complex helpers (float2 = re, im)
+// complex arithmetic on packed pairs: cf = (re, im) in one aligned 64-bit VGPR pair.
+//
+// A wave64 VALU instruction occupies its SIMD for ~4 cycles unless four or more waves of that SIMD have VALU work
+// ready at the same time (measured: tools/probes/valu_rate.hip; this kernel sits at ~4.1 cycles per instruction, PMC
+// SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU), and a packed v_pk_{add,mul,fma}_f32 performs two float operations in such a
+// slot.  A complex add is one packed add, a complex multiply is a packed multiply plus a packed fma, and a
+// multiplication by -i costs nothing: it is folded into the operand-select / negate modifiers of the consuming
+// instruction.  The compiler only derives the broadcast and whole-vector-negate forms of those modifiers from vector
+// code, so the swizzled forms are written out as inline assembly.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 w) {
-    return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+typedef float cf __attribute__((ext_vector_type(2)));
+
+// a + (-i) b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ cf add_mi(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a - (-i) b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ cf sub_mi(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + conj(b) = (a.x + b.x, a.y - b.y)   and   a - conj(b) = (a.x - b.x, a.y + b.y)
+__device__ __forceinline__ cf add_conj(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cf sub_conj(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a * w (complex): t = (a.x w.x, a.y w.x);  r = (t.x - a.y w.y, t.y + a.x w.y)
+__device__ __forceinline__ cf cmul(cf a, cf w) {
+    cf r;   // one asm statement: between two of them the hazard recognizer pads an s_nop
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+        : "=&v"(r) : "v"(a), "v"(w));
+    return r;
 }
 
-// cos/sin(2*pi*i/32), i = 0..15 (compile-time twiddles of the in-register radix butterflies)
-__device__ constexpr float kCos32[16] = {
-    1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
-    0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f,
-    0.0f, -0.19509032201612826785f, -0.38268343236508977173f, -0.55557023301960222474f,
-    -0.70710678118654752440f, -0.83146961230254523708f, -0.92387953251128675613f, -0.98078528040323044913f};
-__device__ constexpr float kSin32[16] = {
-    0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
-    0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f,
-    1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
-    0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
+// cos/sin(2*pi*i/32), i = 0..7 (compile-time twiddles of the in-register radix butterflies, first quadrant)
+__device__ constexpr float kCos32[8] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                                        0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f,
+                                        0.19509032201612826785f};
+__device__ constexpr float kSin32[8] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
+                                        0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f,
+                                        0.98078528040323044913f};
 
-// v * exp(-2*pi*i*J/R), J < R/2, R in {2,4,8,16,32}; trivial factors cost no multiply
-template <int J, int R>
-__device__ __forceinline__ float2 mul_w(float2 v) {
-    constexpr int idx = J * (32 / R);
+// v * exp(-2*pi*i*Q/R) for a first-quadrant exponent (Q < R/4); exponents R/4 <= J < R/2 are this times a pending -i
+template <int Q, int R>
+__device__ __forceinline__ cf mul_w_q1(cf v) {
+    constexpr int idx = Q * (32 / R);
+    static_assert(idx >= 0 && idx < 8, "first quadrant");
     if constexpr (idx == 0) {
         return v;
-    } else if constexpr (idx == 8) {
-        return make_float2(v.y, -v.x);
-    } else if constexpr (idx == 4) {
-        constexpr float c = 0.70710678118654752440f;
-        return make_float2((v.x + v.y) * c, (v.y - v.x) * c);
-    } else if constexpr (idx == 12) {
-        constexpr float c = 0.70710678118654752440f;
-        return make_float2((v.y - v.x) * c, -(v.x + v.y) * c);
-    } else {
-        constexpr float wr = kCos32[idx], wi = -kSin32[idx];
-        return make_float2(v.x * wr - v.y * wi, v.x * wi + v.y * wr);
+    } else if constexpr (idx == 4) {   // (1 - i)/sqrt(2) * v = (v + (-i) v)/sqrt(2)
+        return add_mi(v, v) * 0.70710678118654752440f;
+    } else {                           // (c - i s)(x + i y) = (c x + s y) + i (c y - s x)
+        constexpr float c = kCos32[idx], sn = kSin32[idx];
+        const cf t = v * c;
+        const cf sv = {sn, sn};
+        cf r;
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(v), "v"(sv), "v"(t));
+        return r;
     }
 }
 
-// In-register decimation-in-frequency DFT of R points, natural order in and out (the bit reversal is a
-// compile-time renaming of registers).  R = 8: 56 VALU ops, R = 16: 168.
-template <int R>
-__device__ __forceinline__ void dft(float2 (&x)[R]);
+// In-register decimation-in-frequency DFT of R points, natural order in and out (the bit reversal is a compile-time
+// renaming of registers).  UR: the upper half of the inputs carries a pending factor -i (the twiddles W_R^J with
+// J >= R/4 of the layer before); it is absorbed by this layer's butterflies.  R = 8: 28 packed VALU ops, R = 16: 84.
+template <int R, bool UR>
+__device__ __forceinline__ void dft(cf (&x)[R]);
 
-template <int R, int J>
+template <int R, bool UR, int J>
 struct DifLayer {
-    static __device__ __forceinline__ void run(const float2 (&x)[R], float2 (&a)[R / 2], float2 (&b)[R / 2]) {
-        a[J] = cadd(x[J], x[J + R / 2]);
-        b[J] = mul_w<J, R>(csub(x[J], x[J + R / 2]));
-        if constexpr (J + 1 < R / 2) DifLayer<R, J + 1>::run(x, a, b);
+    static __device__ __forceinline__ void run(const cf (&x)[R], cf (&a)[R / 2], cf (&b)[R / 2]) {
+        const cf lo = x[J], hi = x[J + R / 2];
+        a[J] = UR ? add_mi(lo, hi) : lo + hi;
+        const cf d = UR ? sub_mi(lo, hi) : lo - hi;
+        constexpr int Q = J % (R / 4);   // W_R^J = (-i) W_R^(J - R/4) for J >= R/4: the -i stays pending (dft<R/2, true>)
+        b[J] = mul_w_q1<Q, R>(d);
+        if constexpr (J + 1 < R / 2) DifLayer<R, UR, J + 1>::run(x, a, b);
     }
 };
 
-template <int R>
-__device__ __forceinline__ void dft(float2 (&x)[R]) {
+template <int R, bool UR = false>
+__device__ __forceinline__ void dft(cf (&x)[R]) {
     if constexpr (R == 2) {
-        const float2 a = x[0], b = x[1];
-        x[0] = cadd(a, b);
-        x[1] = csub(a, b);
+        const cf a = x[0], b = x[1];
+        x[0] = UR ? add_mi(a, b) : a + b;
+        x[1] = UR ? sub_mi(a, b) : a - b;
     } else if constexpr (R > 2) {
-        float2 a[R / 2], b[R / 2];
-        DifLayer<R, 0>::run(x, a, b);
-        dft<R / 2>(a);
-        dft<R / 2>(b);
+        cf a[R / 2], b[R / 2];
+        DifLayer<R, UR, 0>::run(x, a, b);
+        dft<R / 2, false>(a);
+        dft<R / 2, true>(b);   // b[J], J >= R/4, still lacks its factor -i
 #pragma unroll
         for (int q = 0; q < R / 2; ++q) {
             x[2 * q] = a[q];
@@ -119,6 +154,7 @@ __device__ __forceinline__ void wave_sync() {
 struct __attribute__((packed, aligned(4))) f2u {
     float x, y;
 };
+__device__ __forceinline__ cf to_cf(const f2u& v) { return cf{v.x, v.y}; }
 
 // ------------------------------------------------------------------------------------------------------------
 // per-size configuration (mirrors tools/fft_model.py CONFIGS; layouts found by its conflict search)
@@ -126,19 +162,13 @@ struct __attribute__((packed, aligned(4))) f2u {
 // TLOC: where the lane tables (window pairs, stage-1/2 twiddles, post-pass twiddles; [4][P][64] float2) live:
 //   0 = read from global memory (L1/L2) at every use, 1 = staged once per workgroup into LDS and read from there,
 //   2 = loaded once per wave into registers.
-// XCH1: exchange 1 through LDS (0) or through lane swaps in registers (1, 8x8x8 plan only).
-// ZX  : partner fetch of the post pass through LDS (0) or ds_bpermute (1, 8x8x8 plan only).
 template <int N_, int R1_, int R2_, int R3_, int L_, int S1_, int AX_, int AY_, int AZ_, int WPB_, int TLOC_, int WPS_,
-          int XCH1_ = 0, int ZX_ = 0, int PF_ = 1, int ABL_ = 0, bool NT_ = true, bool PAIR_ = true>
+          int PF_ = 1, int ABL_ = 0, bool NT_ = true>
 struct Cfg {
-    // PAIR: post pass computes X[k] and X[M-k] together from one (S, D, W*D) butterfly: each lane handles the pairs of
-    // its lower P/2 registers and stores both bins (8 fewer VALU ops per pair, half the partner fetches).
-    static constexpr bool PAIR = PAIR_ && ZX_ == 0;
     static constexpr bool NT = NT_;                  // non-temporal (streaming) stores of the dB columns
     static constexpr int ABLX = ABL_;                // development ablations: 1 = memory traffic only, 2 = compute only, 3 = stamps,
                                                      // 11..14 = memory-only sub-modes (no table staging / half loads / 16-B stores / all)
     static constexpr int ABL = ABL_ >= 11 ? 1 : ABL_;
-    static constexpr int XCH1 = XCH1_, ZX = ZX_;
     static constexpr int PF = PF_;                   // software-prefetch depth in FFTs (1 or 2)
     static constexpr int N = N_, M = N_ / 2, R1 = R1_, R2 = R2_, R3 = R3_, L = L_;
     static constexpr int P = M / L;                  // complex values per lane
@@ -164,33 +194,31 @@ struct Cfg {
     static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget of one CU");
 };
 
-using Cfg512 = Cfg<512, 8, 8, 4, 32, 36, 4, 33, 1, 8, 1, 2, 0, 0, 1>;
+using Cfg512 = Cfg<512, 8, 8, 4, 32, 36, 4, 33, 1, 8, 1, 2>;   // (a 80-VGPR budget = 3 workgroups per CU measured no faster)
 // default 1024-point plan: both exchanges through LDS, prefetch depth 1, 8 waves per workgroup (fastest of the
 // measured variants, DESIGN.md "Kernel variants")
-using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1>;
+using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2>;
 #ifdef JSG_DEV_VARIANTS
 // development variants of the 1024-point plan (selected with JSG_1024_VARIANT, see tools/sweep_variants.sh); compiled
 // only into development builds (JSG_DEV_VARIANTS=1 python -m jadespectrogram_amd._build)
-using Cfg1024B = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 0, 2>;
-using Cfg1024D = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 1, 1>;
-using Cfg1024G = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 1>;
-using Cfg1024H = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 2>;
-using Cfg1024G1 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 0, 2, 0, 0, 1, 11>;
-using Cfg1024G2 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 12>;
-using Cfg1024G3 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 13>;
-using Cfg1024G4 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 0, 2, 0, 0, 1, 14>;
-using Cfg1024S = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 3>;
-using Cfg1024N = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 0, false>;
-using Cfg1024U = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 0, true, false>;
-using Cfg1024M = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 0, 0, 1, 1, true>;
+using Cfg1024B = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 2>;           // prefetch depth 2
+using Cfg1024G = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 1>;        // ablation: memory traffic only
+using Cfg1024H = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 2>;        // ablation: compute only
+using Cfg1024G1 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 0, 2, 1, 11>;      // memory-only sub-modes
+using Cfg1024G2 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 12>;
+using Cfg1024G3 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 13>;
+using Cfg1024G4 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 0, 2, 1, 14>;
+using Cfg1024S = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 3>;        // s_memtime stamps
+using Cfg1024N = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 0, false>; // cached (not non-temporal) stores
+using Cfg1024M = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 1, true>;
 // development variants of the 2048-point plan (JSG_2048_VARIANT)
 using Cfg2048T0 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 0, 1>;          // tables from global memory (L1/L2), no LDS copy
 using Cfg2048W8 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 8, 1, 2>;          // 8-wave workgroups
 using Cfg2048T0W8 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 8, 0, 2>;
 #endif
 using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 1, 1>;   // (12-wave workgroups measured slower: 303 vs 410 Mframes/s)
-using Cfg4096 = Cfg<4096, 16, 8, 16, 128, 144, 1, 272, 17, 8, 1, 1, 0, 0, 1>;    // two wavefronts per frame
-using Cfg8192 = Cfg<8192, 16, 16, 16, 256, 272, 1, 272, 17, 8, 0, 1, 0, 0, 1>;   // four wavefronts per frame
+using Cfg4096 = Cfg<4096, 16, 8, 16, 128, 144, 1, 272, 17, 8, 1, 1>;    // two wavefronts per frame
+using Cfg8192 = Cfg<8192, 16, 16, 16, 256, 272, 1, 272, 17, 8, 0, 1>;   // four wavefronts per frame
 
 struct StftKArgs {
     const float* in;
@@ -229,24 +257,6 @@ __device__ __forceinline__ float mix_combine(float acc, float pw) {
     else return pw;                                             // one channel per column: 0 + pw == pw exactly
 }
 
-// Cross-lane helpers for the register-only exchange (gfx950: v_permlane32_swap / v_permlane16_swap / DPP row_ror).
-__device__ __forceinline__ void swap_lane32(float& a, float& b) {   // a[lanes 32..63] <-> b[lanes 0..31]
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    a = __uint_as_float(r[0]);
-    b = __uint_as_float(r[1]);
-}
-__device__ __forceinline__ void swap_lane16(float& a, float& b) {   // a[odd 16-lane rows] <-> b[even rows]
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    a = __uint_as_float(r[0]);
-    b = __uint_as_float(r[1]);
-}
-__device__ __forceinline__ void swap_lane8(float& a, float& b, bool hi) {   // a[lane bit3 = 1] <-> b[lane bit3 = 0]
-    const float send = hi ? a : b;
-    const float recv = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(send), 0x128 /*row_ror:8*/, 0xf, 0xf, false));
-    a = hi ? recv : a;
-    b = hi ? b : recv;
-}
-
 // MIXOP: 0 sum over a channel range (AbsMean, Sum), 1 max, 2 min, 3 exactly one channel per column (mono, Left, Right,
 // per-channel): the channel bookkeeping folds away and every iteration ends in the store epilogue, which makes the
 // number of vector-memory instructions per iteration a compile-time fact -- the s_waitcnt the compiler places in
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
     a.iters = k_iters; a.regular = k_flags & 1; a.per_channel = (k_flags >> 1) & 1; a.c_begin = k_c_begin; a.c_end = k_c_end;
     // Two distinct LDS objects on purpose: the (read-only) lane tables and the exchange buffers.  With one object
     // the compiler must assume that a table read may alias an exchange store and serialises them.
-    __shared__ __attribute__((aligned(16))) float2 s_tab[C::TLOC == 1 ? C::TAB_ELEMS : 2];
+    __shared__ __attribute__((aligned(16))) cf s_tab[C::TLOC == 1 ? C::TAB_ELEMS : 2];
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int L = C::L, P = C::P, M = C::M, R1 = C::R1, R2 = C::R2, R3 = C::R3;
     constexpr int U1 = C::U1, U2 = C::U2, U3 = C::U3;
@@ -274,7 +284,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
     const int ll = L <= 64 ? lane % L : (wave % C::WPF) * 64 + lane;
     const int sub = L <= 64 ? lane / L : 0;
     const int slot0 = L <= 64 ? wave * C::SUB : wave / C::WPF;   // wave-uniform part of the slot
-    float2* const lds = reinterpret_cast<float2*>(smem_raw) + (slot0 + sub) * C::LDS_ELEMS;
+    cf* const lds = reinterpret_cast<cf*>(smem_raw) + (slot0 + sub) * C::LDS_ELEMS;
     constexpr int TL = C::TL;
     const int tl = L <= 64 ? lane : ll;                           // index into a lane-table row
     unsigned long long st0 = 0, st1 = 0, st2 = 0;
@@ -344,7 +354,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    const float2* tWin;
+    const cf* tWin;
     if constexpr (C::TLOC == 1) {
         v4f* s4 = reinterpret_cast<v4f*>(s_tab) + threadIdx.x;
 #pragma unroll
@@ -353,13 +363,13 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
         __syncthreads();
         tWin = s_tab + tl;
     } else {
-        tWin = a.tab + tl;
+        tWin = reinterpret_cast<const cf*>(a.tab) + tl;
     }
-    const float2* const tTw1 = tWin + P * TL;
-    const float2* const tTw2 = tTw1 + P * TL;
-    const float2* const tPost = tTw2 + P * TL;
+    const cf* const tTw1 = tWin + P * TL;
+    const cf* const tTw2 = tTw1 + P * TL;
+    const cf* const tPost = tTw2 + P * TL;
     constexpr int NR = C::TLOC == 2 ? P : 1;
-    float2 rWin[NR], rTw1[NR], rTw2[NR], rPost[NR];
+    cf rWin[NR], rTw1[NR], rTw2[NR], rPost[NR];
     if constexpr (C::TLOC == 2) {
 #pragma unroll
         for (int j = 0; j < P; ++j) {
@@ -390,8 +400,6 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
         const int t3 = ll + L * w;
         e2r[w] = (t3 % R1) * C::AX + (t3 / R1) * C::AY;
     }
-    const bool lane_bit3 = (lane & 8) != 0;
-    const int zsrc = ((64 - lane) & 63) * 4;   // ds_bpermute address of the lane holding Z[M-k]
 
     float acc[P];
     float accNy;
@@ -407,7 +415,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
     auto process = [&](auto& raw, int s, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
         // ---- window multiply ----
-        float2 x[P];
+        cf x[P];
         if constexpr (C::ABL == 2) {
 #pragma unroll
             for (int m = 0; m < P; ++m) { raw[m].x = __int_as_float(0x3f800000 + lane + m + s); raw[m].y = 0.5f; }
@@ -419,8 +427,8 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
         }
 #pragma unroll
         for (int m = 0; m < P; ++m) {
-            const float2 w = (C::ABLX == 11 || C::ABLX == 14) ? make_float2(0.5f, 0.25f) : JSG_T(rWin, tWin, m);
-            x[m] = make_float2(raw[m].x * w.x, raw[m].y * w.y);
+            const cf w = (C::ABLX == 11 || C::ABLX == 14) ? cf{0.5f, 0.25f} : JSG_T(rWin, tWin, m);
+            x[m] = to_cf(raw[m]) * w;
         }
         if constexpr (C::ABL == 3) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -441,58 +449,27 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
         }
         if constexpr (C::ABL != 1) {
         // ---- stage 1: radix-R1 over n1, twiddle W_{R1R2}^{n2 k1}, exchange 1 ----
-        if constexpr (C::XCH1 == 1) {
-            // register-only exchange: transpose lane bits 5:3 with the register index (lane (b,c) reg p ->
-            // lane (p,c) reg b) by three swap steps, no LDS traffic and no LDS round-trip latency
-            static_assert(C::XCH1 == 0 || (L == 64 && P == 8 && R1 == 8 && R2 == 8 && R3 == 8), "swap exchange is for the 8x8x8 plan");
-            float2 t[R1];
 #pragma unroll
-            for (int n1 = 0; n1 < R1; ++n1) t[n1] = x[n1];
+        for (int u = 0; u < U1; ++u) {
+            cf t[R1];
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) t[n1] = x[u + U1 * n1];
             dft<R1>(t);
+            lds[ll + L * u] = t[0];
 #pragma unroll
-            for (int k1 = 1; k1 < R1; ++k1) t[k1] = cmul(t[k1], JSG_T(rTw1, tTw1, k1));
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                swap_lane32(t[p].x, t[p + 4].x);
-                swap_lane32(t[p].y, t[p + 4].y);
-            }
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                if ((p & 2) == 0) {
-                    swap_lane16(t[p].x, t[p + 2].x);
-                    swap_lane16(t[p].y, t[p + 2].y);
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < 8; p += 2) {
-                swap_lane8(t[p].x, t[p + 1].x, lane_bit3);
-                swap_lane8(t[p].y, t[p + 1].y, lane_bit3);
-            }
-#pragma unroll
-            for (int n2 = 0; n2 < R2; ++n2) x[n2] = t[n2];
-        } else {
-#pragma unroll
-            for (int u = 0; u < U1; ++u) {
-                float2 t[R1];
-#pragma unroll
-                for (int n1 = 0; n1 < R1; ++n1) t[n1] = x[u + U1 * n1];
-                dft<R1>(t);
-                lds[ll + L * u] = t[0];
-#pragma unroll
-                for (int k1 = 1; k1 < R1; ++k1) lds[k1 * C::S1 + ll + L * u] = cmul(t[k1], JSG_T(rTw1, tTw1, u * R1 + k1));
-            }
-            frame_sync();
-#pragma unroll
-            for (int v = 0; v < U2; ++v) {
-#pragma unroll
-                for (int n2 = 0; n2 < R2; ++n2) x[v * R2 + n2] = lds[e1r[v] + n2 * R3];
-            }
-            frame_sync();
+            for (int k1 = 1; k1 < R1; ++k1) lds[k1 * C::S1 + ll + L * u] = cmul(t[k1], JSG_T(rTw1, tTw1, u * R1 + k1));
         }
+        frame_sync();
+#pragma unroll
+        for (int v = 0; v < U2; ++v) {
+#pragma unroll
+            for (int n2 = 0; n2 < R2; ++n2) x[v * R2 + n2] = lds[e1r[v] + n2 * R3];
+        }
+        frame_sync();
         // ---- stage 2: radix-R2 over n2, twiddle W_M^{n3 (k1 + R1 k2)}, exchange 2 ----
 #pragma unroll
         for (int v = 0; v < U2; ++v) {
-            float2 t[R2];
+            cf t[R2];
 #pragma unroll
             for (int n2 = 0; n2 < R2; ++n2) t[n2] = x[v * R2 + n2];
             dft<R2>(t);
@@ -507,17 +484,16 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
             for (int n3 = 0; n3 < R3; ++n3) x[w * R3 + n3] = lds[e2r[w] + n3 * C::AZ];
         }
         frame_sync();
-        float2 zp[P];
 #pragma unroll
         for (int w = 0; w < U3; ++w) {
-            float2 t[R3];
+            cf t[R3];
 #pragma unroll
             for (int n3 = 0; n3 < R3; ++n3) t[n3] = x[w * R3 + n3];
             dft<R3>(t);
 #pragma unroll
             for (int k3 = 0; k3 < R3; ++k3) x[w * R3 + k3] = t[k3];
         }
-        if constexpr (C::PAIR) {
+        {
             // ---- paired real-split post pass.  Bin k = ll + L*rho (rho = w + U3*k3).  A lane owns the pairs of its
             // lower registers rho < P/2: (k, M-k); Z[M-k] is the upper register P-1-rho of lane L-ll (lane 0: its own
             // register P-rho, and Z[M] = Z[0]).  With the window pre-scaled by 1/2 and T = (-i W_N^k) (Z[k] - conj Z[M-k]):
@@ -529,26 +505,22 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
             for (int rho = P / 2; rho < P; ++rho) lds[ll + L * rho] = x[reg_of(rho)];
             if (ll == 0) lds[M] = x[0];   // Z[M] := Z[0]
             frame_sync();
-            float2 zq[P / 2];
+            cf zq[P / 2];
 #pragma unroll
             for (int rho = 0; rho < P / 2; ++rho) zq[rho] = lds[M - (ll + L * rho)];
             frame_sync();   // the next FFT's exchange stores must stay behind these loads
 #pragma unroll
             for (int rho = 0; rho < P / 2; ++rho) {
-                const float2 z = x[reg_of(rho)], p = zq[rho];
-                const float2 S = make_float2(z.x + p.x, z.y - p.y);
-                const float2 D = make_float2(z.x - p.x, z.y + p.y);
-                const float2 W = JSG_T(rPost, tPost, reg_of(rho));
-                const float tx = W.x * D.x - W.y * D.y;
-                const float ty = W.x * D.y + W.y * D.x;
-                const float ax = S.x + tx, ay = S.y + ty;
-                const float bx = S.x - tx, by = S.y - ty;
-                acc[rho] = mix_combine<MIXOP>(acc[rho], ax * ax + ay * ay);
-                acc[P / 2 + rho] = mix_combine<MIXOP>(acc[P / 2 + rho], bx * bx + by * by);
+                const cf z = x[reg_of(rho)], p = zq[rho];
+                const cf S = add_conj(z, p);
+                const cf T = cmul(sub_conj(z, p), JSG_T(rPost, tPost, reg_of(rho)));
+                const cf xa = S + T, xb = S - T;
+                acc[rho] = mix_combine<MIXOP>(acc[rho], xa.x * xa.x + xa.y * xa.y);
+                acc[P / 2 + rho] = mix_combine<MIXOP>(acc[P / 2 + rho], xb.x * xb.x + xb.y * xb.y);
             }
             {   // bin M/2 (held by the frame's lane 0): the window carries 1/2, so |X|^2 = 4 |Z'|^2.  For single-wave
                 // frames the value is broadcast so that every lane can take part in an unmasked store below.
-                float2 z = x[reg_of(P / 2)];
+                cf z = x[reg_of(P / 2)];
                 if constexpr (L == 64) {
                     z.x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(z.x)));
                     z.y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(z.y)));
@@ -560,49 +532,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
                 }
                 accNy = mix_combine<MIXOP>(accNy, 4.0f * (z.x * z.x + z.y * z.y));
             }
-        } else {
-        // ---- partner fetch Z[M-k] for the real-split post pass ----
-        if constexpr (C::ZX == 1) {
-            // k = lane + 64 k3  ->  M-k = (64-lane) + 64 (7-k3): register 7-k3 of lane 64-lane; lane 0 pairs with
-            // itself: Z[64 (8-k3)], i.e. its own register (8-k3) mod 8 (Z[M] = Z[0])
-            static_assert(C::ZX == 0 || (L == 64 && P == 8 && U3 == 1), "bpermute partner fetch is for the 8x8x8 plan");
-#pragma unroll
-            for (int k3 = 0; k3 < 8; ++k3) {
-                const float2 own = (lane == 0) ? x[(8 - k3) & 7] : x[7 - k3];
-                zp[k3].x = __uint_as_float(__builtin_amdgcn_ds_bpermute(zsrc, __float_as_uint(own.x)));
-                zp[k3].y = __uint_as_float(__builtin_amdgcn_ds_bpermute(zsrc, __float_as_uint(own.y)));
-            }
-        } else {
-#pragma unroll
-            for (int w = 0; w < U3; ++w) {
-#pragma unroll
-                for (int k3 = 0; k3 < R3; ++k3) lds[ll + L * w + R1 * R2 * k3] = x[w * R3 + k3];
-            }
-            if (ll == 0) lds[M] = x[0];   // Z[M] := Z[0]
-            frame_sync();
-#pragma unroll
-            for (int w = 0; w < U3; ++w) {
-#pragma unroll
-                for (int k3 = 0; k3 < R3; ++k3) zp[w * R3 + k3] = lds[M - (ll + L * w + R1 * R2 * k3)];
-            }
-            frame_sync();   // the next FFT's exchange stores must stay behind these loads
         }
-        // ---- real-split post pass: X[k] = (Z[k] + conj Z[M-k])/2 - i/2 W_N^k (Z[k] - conj Z[M-k]) ----
-#pragma unroll
-        for (int m = 0; m < P; ++m) {
-            const float2 z = x[m], p = zp[m];
-            const float2 S = make_float2(z.x + p.x, z.y - p.y);
-            const float2 D = make_float2(z.x - p.x, z.y + p.y);
-            const float2 W = JSG_T(rPost, tPost, m);
-            const float xr = 0.5f * S.x + (W.x * D.x - W.y * D.y);
-            const float xi = 0.5f * S.y + (W.x * D.y + W.y * D.x);
-            acc[m] = mix_combine<MIXOP>(acc[m], xr * xr + xi * xi);
-        }
-        {   // Nyquist bin X[M] = Re Z0 - Im Z0 (only lane 0 of the frame holds Z[0] in x[0])
-            const float d = x[0].x - x[0].y;
-            accNy = mix_combine<MIXOP>(accNy, d * d);
-        }
-        }   // !PAIR
         }   // ABL != 1
 
         // ---- last channel of this column: mix epilogue + dB + ring store ----
@@ -643,7 +573,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
                     __builtin_nontemporal_store(v1, &d4[64 + ll]);
                     if (ll == 0) __builtin_nontemporal_store(accNy, &dst[M]);
                 }
-            } else if constexpr (C::PAIR) {
+            } else {
                 if (C::ABL == 2 ? (acc[0] == 12345.678f) : true) {
 #pragma unroll
                     for (int rho = 0; rho < P / 2; ++rho) {
@@ -659,20 +589,6 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
                         if constexpr (C::NT) __builtin_nontemporal_store(accNy, &dst[M / 2]);
                         else dst[M / 2] = accNy;
                     }
-                }
-            } else
-            if (C::ABL == 2 ? (acc[0] == 12345.678f) : true) {
-#pragma unroll
-                for (int w = 0; w < U3; ++w) {
-#pragma unroll
-                    for (int k3 = 0; k3 < R3; ++k3) {
-                        if constexpr (C::NT) __builtin_nontemporal_store(acc[w * R3 + k3], &dst[ll + L * w + R1 * R2 * k3]);
-                        else dst[ll + L * w + R1 * R2 * k3] = acc[w * R3 + k3];
-                    }
-                }
-                if (ll == 0) {
-                    if constexpr (C::NT) __builtin_nontemporal_store(accNy, &dst[M]);
-                    else dst[M] = accNy;
                 }
             }
 #pragma unroll
@@ -800,7 +716,7 @@ static void fill_tables(std::vector<float2>& t, const float* window, double amp)
         const int ll = e % L;
         for (int m = 0; m < P; ++m) {   // window pairs: samples 2n, 2n+1 with n = ll + L m
             const int n = ll + L * m;
-            const double a2 = C::PAIR ? 0.5 * amp : amp;   // the paired post pass expects Z/2
+            const double a2 = 0.5 * amp;   // the paired post pass expects Z/2
             t[(0 * P + m) * TL + e] = make_float2(float(double(window[2 * n]) * a2), float(double(window[2 * n + 1]) * a2));
         }
         for (int u = 0; u < C::U1; ++u)
@@ -819,9 +735,8 @@ static void fill_tables(std::vector<float2>& t, const float* window, double amp)
             for (int k3 = 0; k3 < R3; ++k3) {
                 const int k = ll + L * w + R1 * R2 * k3;
                 const double ang = -two_pi * double(k) / double(N);
-                // -i/2 * exp(i ang) = 0.5 sin(ang) - 0.5 i cos(ang); the paired post pass uses -i exp(i ang)
-                const double h = C::PAIR ? 1.0 : 0.5;
-                t[(3 * P + w * R3 + k3) * TL + e] = make_float2(float(h * std::sin(ang)), float(-h * std::cos(ang)));
+                // the paired post pass multiplies by -i exp(i ang) = sin(ang) - i cos(ang)
+                t[(3 * P + w * R3 + k3) * TL + e] = make_float2(float(std::sin(ang)), float(-std::cos(ang)));
             }
     }
 }
@@ -887,6 +802,16 @@ __global__ __launch_bounds__(256) void dev_copy_kernel(const float4* __restrict_
     }
 }
 
+// development only: resident workgroups per CU of the default (single-channel) kernel of a plan size, its LDS and threads
+template <class C>
+static int occupancy_of(int* lds, int* threads) {
+    int nb = 0;
+    *lds = C::LDS_TOTAL;
+    *threads = C::WPB * 64;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_db_kernel<C, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stft_db_kernel<C, 3>, C::WPB * 64, C::LDS_BYTES) != hipSuccess) return -1;
+    return nb;
+}
 extern "C" {
 
 // development only: the same copy with the STFT kernel's access widths (8-byte loads, 4-byte nt stores)
@@ -921,6 +846,17 @@ int jsg_dev_copy_launch(const void* src, void* dst, long long bytes, int blocks,
 
 // development only (not part of include/jsg.h): device buffer for the s_memtime stamps of variant 'S'
 void jsg_dev_set_stamp_buffer(void* p) { g_dev_stamps = static_cast<unsigned long long*>(p); }
+
+int jsg_dev_occupancy(int n, int* lds, int* threads) {
+    switch (n) {
+        case 512: return occupancy_of<Cfg512>(lds, threads);
+        case 1024: return occupancy_of<Cfg1024>(lds, threads);
+        case 2048: return occupancy_of<Cfg2048>(lds, threads);
+        case 4096: return occupancy_of<Cfg4096>(lds, threads);
+        case 8192: return occupancy_of<Cfg8192>(lds, threads);
+    }
+    return -1;
+}
 
 int jsg_device_count(void) {
     int n = 0;
@@ -1067,6 +1003,8 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
     const int bpc = g->blocks_per_cu > 0 ? g->blocks_per_cu : blocks_per_cu;
     long long max_blocks = 256ll * bpc / ny;     // resident workgroups; the rest is looped over
     if (max_blocks < 64) max_blocks = 64;
+    static const int max_blocks_env = [] { const char* e = getenv("JSG_STFT_MAX_BLOCKS"); return e ? atoi(e) : 0; }();   // development
+    if (max_blocks_env > 0) max_blocks = max_blocks_env;
     const int nblk = int(want < max_blocks ? want : max_blocks);
     ka.iters = int((g->n_frames + (long long)nblk * tpb - 1) / ((long long)nblk * tpb));
     const dim3 grid(nblk, ny);
@@ -1078,7 +1016,6 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
             switch (v1024) {
 #ifdef JSG_DEV_VARIANTS
                 case 'B': err = launch_stft<Cfg1024B>(ka, mixop, grid, s); break;
-                case 'D': err = launch_stft<Cfg1024D>(ka, mixop, grid, s); break;
                 case 'G': err = launch_stft<Cfg1024G>(ka, mixop, grid, s); break;
                 case 'H': err = launch_stft<Cfg1024H>(ka, mixop, grid, s); break;
                 case '1': err = launch_stft<Cfg1024G1>(ka, mixop, grid, s); break;

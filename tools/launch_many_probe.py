@@ -6,7 +6,7 @@ import torch
 import jadespectrogram_amd as jsg
 from jadespectrogram_amd import capi
 from jadespectrogram_amd.spectrogram import _stft_args
-n, hop, frames = 1024, 512, 4096
+n, hop, frames = 1024, 512, int(os.environ.get("FRAMES", "4096"))   # FRAMES=8: pure host + command-processor issue rate
 plan = jsg.Plan(n, jsg.window(1, n))
 nbuf = 24
 mode = sys.argv[1] if len(sys.argv) > 1 else "rand"
@@ -32,7 +32,7 @@ for i in range(K):
     a = _stft_args(plan, d_in[i % nbuf], hop, frames, d_out[i % nbuf], feedblocks=2)
     C.memmove(C.byref(arr, i * C.sizeof(capi.StftArgs)), C.byref(a), C.sizeof(capi.StftArgs))
 lib = capi.lib()
-for S in (8,):
+for S in (1, 2, 4, 8, 16):
     streams = [torch.cuda.Stream() for _ in range(S)]
     sarr = (C.c_void_p * S)(*[s.cuda_stream for s in streams])
     lib.jsg_stft_db_launch_many(plan._p, arr, 200, sarr, S); torch.cuda.synchronize()
