@@ -51,8 +51,8 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         if force or _stale(o, [s] + hdrs):
             cmd = [hipcc, "-std=c++17", "-O3", "-fPIC", "-c", s, "-o", o, "-I", os.path.join(ROOT, "include")]
             if src.endswith(".hip"):
-                # -fno-slp-vectorize: on gfx950 a packed v_pk_*_f32 costs two passes of the 32-wide SIMD, i.e. nothing
-                # is gained over two scalar ops, while the packing forces ~140 register moves per FFT
+                # -fno-slp-vectorize: the kernel packs its complex arithmetic into v_pk_*_f32 by hand (re, im in one
+                # register pair); the automatic SLP pass pairs unrelated scalars and pays ~140 register moves per FFT
                 # -amdgpu-kernarg-preload-count: the leading scalar kernel arguments are delivered in SGPRs
                 cmd += [f"--offload-arch={ARCH}", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
                 if dev:
