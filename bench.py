@@ -40,6 +40,17 @@ def synth_audio(channels: int, n_samples: int, fs: float = 48000.0, seed: int = 
     return out
 
 
+def _cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(seconds_budget: float = 12.0, check=None):
     """The oracle's CPU path timed on this host (rank 0, N=1 only): reported baseline, not the target.
     This leg is the only place where bench.py touches oracle/ (test infrastructure); `check` = (samples, dB) of a few
@@ -64,9 +75,21 @@ def cpu_baseline(seconds_budget: float = 12.0, check=None):
             port.stft_db(x, N_FFT, HOP, frames, win)
             done += frames
         dt = time.perf_counter() - t0
-        return {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-                "sample": f"{done} frames of the bench workload through oracle/jsg_oracle_c.c (scalar float32 C port "
-                          f"of Spectrogram::processSynchronBlock, 1 thread) in {dt:.1f} s"}
+        res = {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": f"{done} frames of the bench workload through oracle/jsg_oracle_c.c (scalar float32 C port "
+                         f"of Spectrogram::processSynchronBlock, 1 thread) in {dt:.1f} s",
+               "cpu_model": _cpu_model()}
+        # the same port with OpenMP over frames on every core this process may use (1 thread and all cores)
+        cores = min(len(os.sched_getaffinity(0)), 64)
+        if cores > 1:
+            t0 = time.perf_counter(); done = 0
+            while time.perf_counter() - t0 < seconds_budget / 3:
+                port.stft_db(x, N_FFT, HOP, frames, win, threads=cores)
+                done += frames
+            dt = time.perf_counter() - t0
+            res["all_cores"] = {"value": done / dt, "unit": "frames/s", "cores": cores,
+                                "sample": f"{done} frames, OpenMP over frames, in {dt:.1f} s"}
+        return res
     frames = 8192
     x = synth_audio(1, frames * HOP + N_FFT)
     t0 = time.perf_counter(); done = 0
