@@ -159,7 +159,7 @@ __device__ __forceinline__ cf to_cf(const f2u& v) { return cf{v.x, v.y}; }
 // ------------------------------------------------------------------------------------------------------------
 // per-size configuration (mirrors tools/fft_model.py CONFIGS; layouts found by its conflict search)
 // ------------------------------------------------------------------------------------------------------------
-// TLOC: where the lane tables (window pairs, stage-1/2 twiddles, post-pass twiddles; [4][P][64] float2) live:
+// TLOC: where the lane tables (window pairs, stage-1/2 twiddles, post-pass twiddles; layout: Cfg::TAB_*) live:
 //   0 = read from global memory (L1/L2) at every use, 1 = staged once per workgroup into LDS and read from there,
 //   2 = loaded once per wave into registers.
 template <int N_, int R1_, int R2_, int R3_, int L_, int S1_, int AX_, int AY_, int AZ_, int WPB_, int TLOC_, int WPS_,
@@ -181,7 +181,13 @@ struct Cfg {
     static constexpr int TPB = WPB * 64 / L;         // frames per workgroup per iteration
     static constexpr int TLOC = TLOC_;
     static constexpr int WPS = WPS_;                 // waves per SIMD the register allocator is asked to allow
-    static constexpr int TAB_ELEMS = 4 * P * TL;     // float2 elements of the four lane tables
+    // lane tables (float2 elements): window pairs [P][TL]; stage-1 twiddles W_{R1 R2}^{n2 k1}, which depend on the lane
+    // only through n2 = t1 / R3, stored once per n2 as [R2][TS1] (row stride R1 + 1: the R3 lanes of a group read one
+    // address, the groups of a wave fall into different banks); stage-2 twiddles [P][TL]; post-pass twiddles of the
+    // lower half of the bins [P/2][TL]
+    static constexpr int TS1 = R1_ + 1;
+    static constexpr int TAB_WIN = 0, TAB_TW1 = P * TL, TAB_TW2 = TAB_TW1 + R2_ * TS1, TAB_POST = TAB_TW2 + P * TL;
+    static constexpr int TAB_ELEMS = TAB_POST + (P / 2) * TL;
     static constexpr int e1max = (R1 - 1) * S1 + M / R1;
     static constexpr int e2max = (R1 - 1) * AX + (R2 - 1) * AY + (R3 - 1) * AZ + 1;
     static constexpr int raw = e1max > e2max ? (e1max > M + 1 ? e1max : M + 1) : (e2max > M + 1 ? e2max : M + 1);
@@ -236,7 +242,7 @@ struct StftKArgs {
     long long out_pitch, out_cpitch;
     int ring_w, ring_pos;
     int iters;
-    const float2* tab;   // [4][P][64]: window pairs, stage-1 twiddles, stage-2 twiddles, post-pass twiddles
+    const float2* tab;   // lane tables (Cfg::TAB_* layout): window pairs, stage-1 / stage-2 twiddles, post-pass twiddles
     unsigned long long* stamps;   // development (ABL == 3): 4 s_memtime stamps per wave
     int xcd_remap;                // 1: XCD-aware block remap (default); 0: identity (development A/B)
     int chunked;                  // 0: grid-stride traversal (default); 1: one contiguous chunk per workgroup
@@ -365,18 +371,21 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
     } else {
         tWin = reinterpret_cast<const cf*>(a.tab) + tl;
     }
-    const cf* const tTw1 = tWin + P * TL;
-    const cf* const tTw2 = tTw1 + P * TL;
-    const cf* const tPost = tTw2 + P * TL;
+    const cf* const tTw1 = tWin - tl + C::TAB_TW1;   // compact: [n2][TS1], not indexed by lane
+    const cf* const tTw2 = tWin + C::TAB_TW2;
+    const cf* const tPost = tWin + C::TAB_POST;
+    int tw1row[U1];                                   // row of this lane's butterfly u in the stage-1 table
+#pragma unroll
+    for (int u = 0; u < U1; ++u) tw1row[u] = ((ll + L * u) / R3) * C::TS1;
     constexpr int NR = C::TLOC == 2 ? P : 1;
     cf rWin[NR], rTw1[NR], rTw2[NR], rPost[NR];
     if constexpr (C::TLOC == 2) {
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             rWin[j] = tWin[j * TL];
-            rTw1[j] = tTw1[j * TL];
+            rTw1[j] = tTw1[tw1row[j / R1] + j % R1];
             rTw2[j] = tTw2[j * TL];
-            rPost[j] = tPost[j * TL];
+            if (j < P / 2) rPost[j] = tPost[j * TL];
         }
     }
 #define JSG_T(reg, ptr, j) (C::TLOC == 2 ? reg[C::TLOC == 2 ? (j) : 0] : ptr[(j) * TL])
@@ -457,7 +466,8 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
             dft<R1>(t);
             lds[ll + L * u] = t[0];
 #pragma unroll
-            for (int k1 = 1; k1 < R1; ++k1) lds[k1 * C::S1 + ll + L * u] = cmul(t[k1], JSG_T(rTw1, tTw1, u * R1 + k1));
+            for (int k1 = 1; k1 < R1; ++k1)
+                lds[k1 * C::S1 + ll + L * u] = cmul(t[k1], C::TLOC == 2 ? rTw1[C::TLOC == 2 ? u * R1 + k1 : 0] : tTw1[tw1row[u] + k1]);
         }
         frame_sync();
 #pragma unroll
@@ -513,7 +523,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) void stft_db_kernel(
             for (int rho = 0; rho < P / 2; ++rho) {
                 const cf z = x[reg_of(rho)], p = zq[rho];
                 const cf S = add_conj(z, p);
-                const cf T = cmul(sub_conj(z, p), JSG_T(rPost, tPost, reg_of(rho)));
+                const cf T = cmul(sub_conj(z, p), JSG_T(rPost, tPost, rho));
                 const cf xa = S + T, xb = S - T;
                 acc[rho] = mix_combine<MIXOP>(acc[rho], xa.x * xa.x + xa.y * xa.y);
                 acc[P / 2 + rho] = mix_combine<MIXOP>(acc[P / 2 + rho], xb.x * xb.x + xb.y * xb.y);
@@ -710,34 +720,30 @@ __global__ __launch_bounds__(256) void db_from_power_kernel(const float* p, floa
 template <class C>
 static void fill_tables(std::vector<float2>& t, const float* window, double amp) {
     constexpr int L = C::L, P = C::P, R1 = C::R1, R2 = C::R2, R3 = C::R3, M = C::M, N = C::N, TL = C::TL;
-    t.assign(size_t(4) * P * TL, make_float2(0.f, 0.f));
+    t.assign(size_t(C::TAB_ELEMS), make_float2(0.f, 0.f));
     const double two_pi = 6.283185307179586476925286766559;
+    for (int n2 = 0; n2 < R2; ++n2)   // stage-1 twiddles, one row per n2 (shared by the lanes with t1 / R3 == n2)
+        for (int k1 = 0; k1 < R1; ++k1) {
+            const double ang = -two_pi * double((long long)n2 * k1 % (R1 * R2)) / double(R1 * R2);
+            t[C::TAB_TW1 + n2 * C::TS1 + k1] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
+        }
     for (int e = 0; e < TL; ++e) {   // entry e of a table row belongs to lane-in-frame ll (L = 32: both half-waves)
         const int ll = e % L;
         for (int m = 0; m < P; ++m) {   // window pairs: samples 2n, 2n+1 with n = ll + L m
             const int n = ll + L * m;
             const double a2 = 0.5 * amp;   // the paired post pass expects Z/2
-            t[(0 * P + m) * TL + e] = make_float2(float(double(window[2 * n]) * a2), float(double(window[2 * n + 1]) * a2));
+            t[C::TAB_WIN + m * TL + e] = make_float2(float(double(window[2 * n]) * a2), float(double(window[2 * n + 1]) * a2));
         }
-        for (int u = 0; u < C::U1; ++u)
-            for (int k1 = 0; k1 < R1; ++k1) {
-                const int t1 = ll + L * u, n2 = t1 / R3;
-                const double ang = -two_pi * double((long long)n2 * k1 % (R1 * R2)) / double(R1 * R2);
-                t[(1 * P + u * R1 + k1) * TL + e] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
-            }
         for (int v = 0; v < C::U2; ++v)
             for (int k2 = 0; k2 < R2; ++k2) {
                 const int t2 = ll + L * v, k1 = t2 / R3, n3 = t2 % R3;
                 const double ang = -two_pi * double((long long)n3 * (k1 + R1 * k2) % M) / double(M);
-                t[(2 * P + v * R2 + k2) * TL + e] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
+                t[C::TAB_TW2 + (v * R2 + k2) * TL + e] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
             }
-        for (int w = 0; w < C::U3; ++w)
-            for (int k3 = 0; k3 < R3; ++k3) {
-                const int k = ll + L * w + R1 * R2 * k3;
-                const double ang = -two_pi * double(k) / double(N);
-                // the paired post pass multiplies by -i exp(i ang) = sin(ang) - i cos(ang)
-                t[(3 * P + w * R3 + k3) * TL + e] = make_float2(float(std::sin(ang)), float(-std::cos(ang)));
-            }
+        for (int rho = 0; rho < P / 2; ++rho) {   // bins k = ll + L rho of the lower half: -i exp(i ang) = sin(ang) - i cos(ang)
+            const double ang = -two_pi * double(ll + L * rho) / double(N);
+            t[C::TAB_POST + rho * TL + e] = make_float2(float(std::sin(ang)), float(-std::cos(ang)));
+        }
     }
 }
 
