@@ -222,9 +222,11 @@ using Cfg2048T0 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 0, 1>;          // t
 using Cfg2048W8 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 8, 1, 2>;          // 8-wave workgroups
 using Cfg2048T0W8 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 8, 0, 2>;
 #endif
-using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 1, 1>;   // (12-wave workgroups measured slower: 303 vs 410 Mframes/s)
-using Cfg4096 = Cfg<4096, 16, 8, 16, 128, 144, 1, 272, 17, 8, 1, 1>;    // two wavefronts per frame
-using Cfg8192 = Cfg<8192, 16, 16, 16, 256, 272, 1, 272, 17, 8, 0, 1>;   // four wavefronts per frame
+using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 1, 1>;   // (6-, 8- and 12-wave workgroups measured 4-60 % slower)
+using Cfg4096 = Cfg<4096, 16, 8, 16, 128, 144, 1, 272, 17, 4, 1, 1>;    // two wavefronts per frame, two frames per workgroup
+using Cfg8192 = Cfg<8192, 16, 16, 16, 256, 272, 1, 272, 17, 4, 0, 1>;   // four wavefronts per frame, one frame per workgroup
+// (frames of more than one wavefront exchange through the workgroup barrier, so every further frame in the workgroup joins
+// five barriers per FFT: 8-wave workgroups were 9-15 % slower, 12-wave ones 30 %)
 
 struct StftKArgs {
     const float* in;
