@@ -4,7 +4,24 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import jadespectrogram_amd as jsg
-def t(fn, steps=50):
+def t(fn, steps=48):
+    if os.environ.get("JSG_KBENCH_GRAPH"):
+        # GPU-side time per call with the host taken out: one hipGraph holding `steps` calls, replayed
+        import time
+        s2 = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s2):
+            for _ in range(8): fn()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s2):
+                for _ in range(steps): fn()
+        torch.cuda.synchronize()
+        for _ in range(2): g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10): g.replay()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / (10 * steps) * 1e6
     for _ in range(5): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
