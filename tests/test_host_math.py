@@ -98,3 +98,44 @@ def test_display_freq_rows_vs_oracle(jsg, oracle):
         assert display_freq_rows(*c) == oracle.display_freq_rows(*c), c
     # the plugin's defaults: full band at 48 kHz, H = 1025 -> rows [0, 854): everything up to 20 kHz
     assert display_freq_rows(48000.0, 1025, 1.0, 20000.0) == (0, 854, 854, 171)
+
+
+def test_colormap_range_fuzz_vs_oracle(jsg, oracle):
+    """setValueRange (CColorpalette.cpp:39-54) for arbitrary slider positions: swapped, equal, tiny and huge ranges.
+    The oracle's arithmetic is pinned by the reference-built golden cases above; here the library follows it bit for bit."""
+    from hypothesis import given, settings, strategies as st
+    finite = st.floats(min_value=-1e6, max_value=1e6, allow_nan=False, allow_infinity=False, width=32)
+
+    @settings(max_examples=300, deadline=None)
+    @given(lo=finite, hi=finite, n=st.integers(min_value=2, max_value=4096), same=st.booleans())
+    def check(lo, hi, n, same):
+        if same:
+            hi = lo
+        if lo == hi == 0.0:
+            return   # Min = 0.99*Max = Max: the reference divides by zero here (undefined), not part of the contract
+        p = oracle.OracleColorPalette(n, oracle.CM_JADE)
+        p.set_value_range(lo, hi)
+        want = np.array([p.vmin, p.vmax, p.mult], dtype=np.float32).view(np.uint32)
+        got = np.array(jsg.colormap_range(n, lo, hi), dtype=np.float32).view(np.uint32)
+        assert (got == want).all(), (lo, hi, n)
+
+    check()
+
+
+def test_geometry_fuzz_vs_oracle(jsg, oracle):
+    """hop, ring width and fft-size-from-milliseconds for arbitrary (not only the GUI's) parameter values."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=300, deadline=None)
+    @given(pct=st.floats(min_value=1.0, max_value=100.0), n=st.sampled_from([512, 1024, 2048, 4096, 8192]),
+           fs=st.floats(min_value=8000.0, max_value=384000.0), mem=st.floats(min_value=0.01, max_value=60.0),
+           ms=st.floats(min_value=0.5, max_value=200.0))
+    def check(pct, n, fs, mem, ms):
+        pct, fs, mem, ms = (float(np.float32(v)) for v in (pct, fs, mem, ms))   # the C-ABI takes floats
+        hop = jsg.feed_samples(pct, n)
+        assert hop == oracle.feed_samples(pct, n)
+        if hop > 0:
+            assert jsg.memsize_blocks(mem, fs, hop) == oracle.memsize_blocks(mem, fs, hop)
+        assert jsg.next_power_of_2(ms, fs) == oracle.next_power_of_2(ms, fs)
+
+    check()
