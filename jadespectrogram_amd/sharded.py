@@ -1,4 +1,4 @@
-"""Channel-sharded multi-GPU driver: one process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI).
+"""Channel-sharded (and, for one long stream, time-sharded) multi-GPU driver: one process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI).
 
 The path shards by independent channels/streams: every rank runs the single-GPU engine on its own
 channels and keeps its spectrograms device-local -- NO data-path collective.  The only exchange the reference's
@@ -20,6 +20,30 @@ def shard_channels(n_channels: int, world: int, rank: int) -> range:
     base, extra = divmod(n_channels, world)
     start = rank * base + min(rank, extra)
     return range(start, start + base + (1 if rank < extra else 0))
+
+
+def shard_frames(n_frames: int, feedblocks: int, world: int, rank: int) -> range:
+    """Time-axis partition of ONE long stream ("also legal"): contiguous runs of frames, cut only at
+    multiples of `feedblocks` because the reference restarts its frame offsets at every fft-size block
+    (Spectrogram.cpp:50-55), balanced in blocks; the first (blocks % world) ranks get one more block."""
+    if not (0 <= rank < world) or n_frames < 0 or feedblocks <= 0:
+        raise ValueError("bad shard request")
+    blocks = (n_frames + feedblocks - 1) // feedblocks
+    base, extra = divmod(blocks, world)
+    b0 = rank * base + min(rank, extra)
+    b1 = b0 + base + (1 if rank < extra else 0)
+    return range(min(b0 * feedblocks, n_frames), min(b1 * feedblocks, n_frames))
+
+
+def frame_span(frames: range, n: int, hop: int, feedblocks: int) -> range:
+    """Samples a run of frames reads (frames.start a multiple of feedblocks): its own new samples plus the halo of
+    n - hop samples it shares with the following rank.  Frame j starts at (j // feedblocks)*n + (j % feedblocks)*hop."""
+    if len(frames) == 0:
+        return range(0, 0)
+    if frames.start % feedblocks:
+        raise ValueError("a shard must start on a block boundary")
+    last = frames.stop - 1
+    return range((frames.start // feedblocks) * n, (last // feedblocks) * n + (last % feedblocks) * hop + n)
 
 
 class GpuBackend:
@@ -82,6 +106,17 @@ class ShardedSpectrogram:
     def per_channel(self, local_samples, n_frames: int):
         """Independent spectrograms of the local channels; stays on this rank's device.  No communication."""
         return self.backend.per_channel_db(self.backend.to_device(local_samples), n_frames)
+
+    def time_sharded(self, stream_samples, n_frames: int):
+        """One long stream [channels][samples] (every rank sees the same host array, e.g. a memory-mapped file) cut
+        along time: this rank computes the per-channel columns of shard_frames(...) from its sample span (own samples +
+        halo) and keeps them on its device.  Returns (frames, columns).  No communication."""
+        b = self.backend
+        frames = shard_frames(n_frames, b.feedblocks, self.world, self.rank)
+        span = frame_span(frames, b.n, b.hop, b.feedblocks)
+        if len(frames) == 0:
+            return frames, None
+        return frames, b.per_channel_db(b.to_device(stream_samples[:, span.start:span.stop]), len(frames))
 
     def absmean(self, local_samples, n_frames: int):
         """The reference's AbsMean column over ALL channels; every rank ends up with the full result."""

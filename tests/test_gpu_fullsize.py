@@ -126,6 +126,26 @@ def test_c4_shard_8ch_per_gpu_per_channel(jsg, oracle, torch_cuda):
     assert torch.equal(d_db[:, :H], mixed[:, :H])
 
 
+@pytest.mark.parametrize("n,hop,fb", [(1024, 512, 2), (2048, 512, 4), (1024, 102, 10)])
+def test_time_axis_shards_equal_the_whole_stream(jsg, oracle, torch_cuda, n, hop, fb):
+    """One long stream cut along time into three shards (own samples + halo), each run like one rank would on its GPU:
+    their columns are the columns of the unsharded launch bit for bit (also across the reference's irregular perc10 hop)."""
+    torch = torch_cuda
+    from jadespectrogram_amd.sharded import GpuBackend, frame_span, shard_frames
+    C, F = 2, 3001
+    win = oracle.window(oracle.WIN_HANN, n)
+    d_in = _stream(torch, C, ((F - 1) // fb) * n + ((F - 1) % fb) * hop + n, seed=9)
+    be = GpuBackend(n, hop, win, feedblocks=fb)
+    whole = be.per_channel_db(d_in, F)
+    parts = []
+    for r in range(3):
+        fr = shard_frames(F, fb, 3, r)
+        span = frame_span(fr, n, hop, fb)
+        parts.append(be.per_channel_db(d_in[:, span.start:span.stop].contiguous(), len(fr)))
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(parts, dim=1)[..., :be.H], whole[..., :be.H])
+
+
 def test_c5_stereo_96k_4096_with_colormap(jsg, oracle, torch_cuda):
     torch = torch_cuda
     n, hop, F, C = 4096, 512, 1875, 2           # 87.5 % overlap, 10 s of 96 kHz -> W = 1875 columns

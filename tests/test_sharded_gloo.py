@@ -62,10 +62,14 @@ def _worker(rank, world, port, n_channels, q):
     per = sh.per_channel(x[mine.start:mine.stop], F).numpy()
     gathered = [None] * world
     dist.all_gather_object(gathered, (mine.start, per))
+    # the same stream cut along time instead: every rank takes a run of frames (+ halo) of all channels
+    fr, cols = sh.time_sharded(x, F)
+    tgathered = [None] * world
+    dist.all_gather_object(tgathered, (fr.start, fr.stop, None if cols is None else cols.numpy()))
     tmax = max_over_ranks(1.0 + rank)
     dist.barrier()
     if rank == 0:
-        q.put((mixed, gathered, tmax))
+        q.put((mixed, gathered, tmax, tgathered))
     dist.destroy_process_group()
 
 
@@ -81,6 +85,27 @@ def test_shard_partition_is_balanced_and_complete():
         shard_channels(4, 2, 2)
 
 
+def test_time_shards_cover_every_frame_once_and_read_the_right_samples():
+    from jadespectrogram_amd.sharded import frame_span, shard_frames
+    for n, hop, fb in ((1024, 512, 2), (2048, 512, 4), (1024, 102, 10), (1024, 1024, 1)):
+        for F in (0, 1, 7, 20, 4096, 4099):
+            for world in (1, 2, 3, 8):
+                parts = [shard_frames(F, fb, world, r) for r in range(world)]
+                assert [j for p in parts for j in p] == list(range(F))
+                assert all(p.start % fb == 0 for p in parts if len(p))
+                blocks = [-(-len(p) // fb) for p in parts]
+                assert max(blocks) - min(blocks) <= 1
+                for p in parts:
+                    span = frame_span(p, n, hop, fb)
+                    starts = [(j // fb) * n + (j % fb) * hop for j in p]
+                    if starts:
+                        assert span.start == min(starts) and span.stop == max(starts) + n
+                    else:
+                        assert len(span) == 0
+    with pytest.raises(ValueError):
+        frame_span(range(1, 3), 1024, 512, 2)
+
+
 def test_world_size_2_absmean_and_per_channel(oracle):
     import torch.multiprocessing as mp
     world, C = 2, 5
@@ -90,7 +115,7 @@ def test_world_size_2_absmean_and_per_channel(oracle):
     procs = [ctx.Process(target=_worker, args=(r, world, port, C, q)) for r in range(world)]
     for p in procs:
         p.start()
-    mixed, gathered, tmax = q.get(timeout=120)
+    mixed, gathered, tmax, tgathered = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -103,6 +128,11 @@ def test_world_size_2_absmean_and_per_channel(oracle):
     ref_per = single.per_channel_db(x, F).numpy()
     got = np.concatenate([g[1] for g in sorted(gathered, key=lambda t: t[0])], axis=0)
     assert (got.view(np.uint32) == ref_per.view(np.uint32)).all()
+    # time-axis shards: consecutive, complete, and their columns are the single-process columns bit for bit
+    tg = sorted(tgathered, key=lambda t: t[0])
+    assert tg[0][0] == 0 and tg[-1][1] == F and all(a[1] == b[0] for a, b in zip(tg, tg[1:]))
+    got_t = np.concatenate([g[2] for g in tg if g[2] is not None], axis=1)
+    assert (got_t.view(np.uint32) == ref_per.view(np.uint32)).all()
     # AbsMean across shards: equal to the reference's sequential float sum up to float32 re-association
     ref_mix = oracle.to_db(oracle.mix_channels(single._power(x, F), oracle.MIX_ABSMEAN))
     assert np.abs(mixed - ref_mix).max() < 1e-4
