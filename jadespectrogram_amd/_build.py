@@ -30,6 +30,34 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name: str, hip_flags, verbose: bool = False) -> str:
+    """DEV: an experimental build of the library with extra device-compile flags (-D switches of jsg_kernels.hip,
+    -mllvm options ...) as tools/variants/libjsg_<name>.so, for tools/abbench (A/B of several builds in one process).
+    The product build below never uses these."""
+    hipcc = _hipcc()
+    vdir = os.path.join(ROOT, "tools", "variants")
+    objdir = os.path.join(PKG, "build", "variants", name)
+    os.makedirs(vdir, exist_ok=True)
+    os.makedirs(objdir, exist_ok=True)
+    out = os.path.join(vdir, f"libjsg_{name}.so")
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        if not src.endswith(".hip"):      # host objects are the product's
+            o = os.path.join(PKG, "build", os.path.splitext(src)[0] + ".o")
+            objs.append(o)
+            continue
+        objs.append(o)
+        cmd = [hipcc, "-std=c++17", "-O3", "-fPIC", "-c", s, "-o", o, "-I", os.path.join(ROOT, "include"),
+               f"--offload-arch={ARCH}", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=16"] + list(hip_flags)
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    subprocess.check_call([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs)
+    return out
+
+
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/* into jadespectrogram_amd/libjsg.so (only what is out of date)."""
     hipcc = _hipcc()
@@ -74,4 +102,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv, verbose=True))
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":      # python -m jadespectrogram_amd._build --variant NAME flags...
+        print(build_variant(sys.argv[2], sys.argv[3:], verbose=True))
+    else:
+        print(build_lib(force="--force" in sys.argv, verbose=True))
