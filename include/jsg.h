@@ -15,8 +15,10 @@
  *   - nothing throws across this boundary; jsg_last_error() gives the text of the last failure.
  *   - an engine is bound to the HIP device that is current when it is created; one engine per GPU,
  *     one process per GPU for multi-GPU use (channels/streams are sharded, no collective needed).
- *   - threading: one producer thread (process_*) and one consumer thread (get_mem / display_*),
- *     serialised internally by a mutex (the reference's m_protect, made to cover the readers too).
+ *   - threading: one producer thread (process_*) and one consumer thread (get_mem / display_* / setters).
+ *     jsg_process_block never waits for the consumer: readers take their snapshot of the ring on a second HIP
+ *     stream and hold the state lock only while they enqueue; what follows them waits on the GPU, not on the
+ *     audio thread.  Setters quiesce the engine (the reference's m_protect around setFFTSize, Spectrogram.cpp:162).
  *   - there is NO CPU fallback: every compute entry point fails with JSG_ERR_HIP / JSG_ERR_NO_DEVICE
  *     when no gfx950 device is usable.
  */
@@ -30,7 +32,7 @@
 extern "C" {
 #endif
 
-#define JSG_ABI_VERSION 1
+#define JSG_ABI_VERSION 2
 
 typedef enum jsg_status {
     JSG_OK = 0,
@@ -131,6 +133,8 @@ typedef struct jsg_stft_args {
     int32_t blocks_per_cu;   /* 0: default (up to 8 workgroups per CU, the rest of the frames is looped over); smaller values make
                                 fewer, longer-lived workgroups that prefetch their next frame -- better when several
                                 launches run concurrently, worse for one launch alone */
+    int64_t in_samples;      /* floats of every channel row that may be read; the launch is refused (JSG_ERR_INVALID) when
+                                its last frame would read past them.  0: unknown, not checked */
 } jsg_stft_args;
 int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* args, void* stream);
 
@@ -177,6 +181,10 @@ typedef struct jsg_engine jsg_engine;
 /* Spectrogram::Spectrogram() defaults (Spectrogram.cpp:16-24): fs 48000, n 1024, feed 100 %, 1 s memory,
  * Hann, AbsMean.  `channels` is explicit (the plugin never calls setchannels). */
 int jsg_create(jsg_engine** out, int channels);
+/* The same on an explicit HIP device (0 .. jsg_device_count()-1) instead of the calling thread's current one: what a
+ * single-process host that drives several GPUs uses, one engine per device ("Several GPUs"). */
+int jsg_create_on_device(jsg_engine** out, int channels, int device);
+int jsg_get_device(const jsg_engine* e);
 int jsg_destroy(jsg_engine* e);
 const char* jsg_last_error(const jsg_engine* e);   /* e may be NULL: last error of the calling thread */
 
@@ -215,6 +223,11 @@ int jsg_process_blocks_device(jsg_engine* e, const float* d_samples, int64_t pit
  * buffer; copies all columns when at least a ring-full is new, else only the new ones (in place,
  * wrap-aware); returns the new-column count and zeroes it, -1 on size mismatch. */
 int jsg_get_mem(jsg_engine* e, float* dst, int dst_columns, int* pos);
+/* The same into the reference's own container shape, vector<vector<float>> mem[W][H] (Spectrogram.h:144): rows[c]
+ * points to the row_len = n/2+1 floats of column c (a NULL row is skipped); only the new columns are touched. */
+int jsg_get_mem_rows(jsg_engine* e, float* const* rows, int n_rows, int row_len, int* pos);
+/* Extension: all columns of the ring as they are now, without consuming the new-column counter (returns the counter). */
+int jsg_peek_mem(jsg_engine* e, float* dst, int dst_columns, int* pos);
 /* Device pointer / geometry of the dB ring (stays valid until the next setter). */
 int jsg_ring_device(jsg_engine* e, float** d_ring, int64_t* pitch, int* width, int* pos);
 int jsg_sync(jsg_engine* e);

@@ -38,7 +38,7 @@ class StftArgs(C.Structure):
                 ("feedblocks", C.c_int32), ("mix_mode", C.c_int32), ("first_frame", C.c_int64),
                 ("n_frames", C.c_int64), ("out_db", C.c_void_p), ("out_pitch", C.c_int64),
                 ("out_channel_pitch", C.c_int64), ("ring_width", C.c_int32), ("ring_pos", C.c_int32),
-                ("linear_out", C.c_int32), ("blocks_per_cu", C.c_int32)]
+                ("linear_out", C.c_int32), ("blocks_per_cu", C.c_int32), ("in_samples", C.c_int64)]
 
 
 class ColormapArgs(C.Structure):
@@ -68,6 +68,8 @@ SIGNATURES = {
     "jsg_colormap_launch": (C.c_int, [C.POINTER(ColormapArgs), _P]),
     "jsg_db_from_power_launch": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
     "jsg_create": (C.c_int, [C.POINTER(_P), C.c_int]),
+    "jsg_create_on_device": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int]),
+    "jsg_get_device": (C.c_int, [_P]),
     "jsg_destroy": (C.c_int, [_P]),
     "jsg_last_error": (C.c_char_p, [_P]),
     "jsg_set_samplerate": (C.c_int, [_P, C.c_float]),
@@ -94,6 +96,8 @@ SIGNATURES = {
     "jsg_process_blocks": (C.c_int, [_P, _P, C.c_int64, C.c_int]),
     "jsg_process_blocks_device": (C.c_int, [_P, _P, C.c_int64, C.c_int]),
     "jsg_get_mem": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
+    "jsg_get_mem_rows": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "jsg_peek_mem": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     "jsg_ring_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "jsg_sync": (C.c_int, [_P]),
     "jsg_stream": (_P, [_P]),

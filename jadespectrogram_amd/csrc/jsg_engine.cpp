@@ -15,11 +15,26 @@
 //                                  recolour write whole cache lines (C5 image: 8.2 instead of 10.2 us).
 //   d_lut   [n_colors] int32       CColorPalette table.
 //   h_pin   (host, page-locked)    8 slots of [channels][n] floats: staging ring of processSynchronBlock.
+//   h_mem   (host, page-locked)    [planes][W][H] floats: landing area of getMem's device-to-host copies.
+//
+// Threads (reference: audio thread = producer, message thread = consumer and setters):
+//   mu      state lock.  Held only while counters are read/updated and work is ENQUEUED -- never across a stream
+//           synchronisation or a blocking copy, except by the setters (reconfiguration quiesces both streams; the
+//           reference holds m_protect across setFFTSize too, Spectrogram.cpp:162-167).
+//   rd_mu   serialises the readers (getMem / display ticks) with each other and with the setters; a reader keeps it
+//           while it waits for its copies, the producer never takes it.  Lock order: rd_mu, then mu.
+//   stream  compute stream: H2D of the block, stft_db_kernel, tail copy.
+//   rstream read-out stream: copies of ring columns, colour kernel, image copies.  A reader records an event on
+//           `stream`, lets `rstream` wait for it (so it sees every column produced before the call), enqueues its ring
+//           reads, and makes `stream` wait for the event behind those reads: later kernels start after the snapshot
+//           was taken -- a dependency on the GPU, not on the audio thread.  jsg_process_block therefore never waits
+//           for a reader: its worst case is the mutex hand-over of an enqueue section (microseconds).
 //
 // There is no CPU compute path here: without a usable HIP device every entry point reports an error.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <mutex>
@@ -57,9 +72,15 @@ inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 }  // namespace
 
 struct jsg_engine {
-    std::mutex mu;
+    std::mutex mu;      // state + enqueue sections
+    std::mutex rd_mu;   // readers and setters (taken before mu)
+    std::mutex err_mu;  // the error text only
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // compute
+    hipStream_t rstream = nullptr;   // read-out
+    hipEvent_t ev_ring = nullptr;    // "every column produced so far" (recorded on stream, awaited by rstream)
+    hipEvent_t ev_read = nullptr;    // "the ring has been read" (recorded on rstream, awaited by stream)
+    hipEvent_t ev_host = nullptr;    // "getMem's columns have arrived in h_mem" (recorded on rstream, awaited by the reader)
     std::string err;
 
     // configuration (reference ctor defaults, Spectrogram.cpp:16-24)
@@ -76,9 +97,11 @@ struct jsg_engine {
     float power_scale = 1.f;
     std::vector<float> window;
 
-    // derived geometry
+    // derived geometry; the atomics mirror W, H, n and the channel count for the lock-free getters
     int hop = 1024, W = 0, H = 513;
     int64_t pitch = 0;
+    std::atomic<int> a_W{0}, a_H{513}, a_n{1024}, a_channels{2}, a_hop{1024}, a_feedblocks{1};
+    std::atomic<float> a_fs{48000.f};
 
     // device state
     jsg_plan* plan = nullptr;
@@ -89,6 +112,7 @@ struct jsg_engine {
     int in_cap_blocks = 0;
     int mem_counter = 0;
     long long new_entry = kNewEntrySentinel;
+    unsigned long long generation = 0;   // bumped by every reconfiguration (buildmem)
 
     // pinned staging ring of processSynchronBlock (audio thread): the block is copied into page-locked memory and
     // leaves for the GPU with an asynchronous DMA, so the caller never waits for the device
@@ -98,7 +122,14 @@ struct jsg_engine {
     hipEvent_t pin_done[kPinSlots] = {};
     unsigned pin_next = 0;
 
-    // display
+    // getMem (readers only, under rd_mu): d_snap takes a device-side copy of the wanted ring columns (microseconds; the
+    // only part later kernels have to wait for), h_mem is the page-locked landing area of the slow copy across PCIe
+    float* d_snap = nullptr;
+    size_t d_snap_floats = 0;
+    float* h_mem = nullptr;
+    size_t h_mem_floats = 0;
+
+    // display (d_img and the flags below belong to the readers: rd_mu; the setters hold it too)
     int n_colors = 256, scheme = JSG_CM_JADE;   // CColorPalette(256,6), Spectrogram.cpp:337
     std::vector<int32_t> lut;
     int32_t* d_lut = nullptr;
@@ -107,18 +138,36 @@ struct jsg_engine {
     int64_t img_pitch = 0;   // pixels per device image row (img_w rounded up to 32)
     bool recompute_all = true;
     bool running = true;
+    // what the caller's image holds after the last jsg_display_update (fixed display: only changed columns are copied)
+    const uint32_t* host_img = nullptr;
+    int64_t host_pitch = 0;
+    bool host_fixed_valid = false;
+    int host_cursor_pos = 0, host_cursor_w = 0;
 
     int fail(int code, const std::string& what) {
-        err = what;
+        {
+            std::lock_guard<std::mutex> lk(err_mu);
+            err = what;
+        }
         tls_error() = what;
         return code;
     }
     int fail_hip(hipError_t e, const char* where) {
         const int code = jsg_fail_hip(e, where);
+        std::lock_guard<std::mutex> lk(err_mu);
+        err = tls_error();
+        return code;
+    }
+    int fail_tls(int code) {   // a stateless entry point failed and left its text in tls_error()
+        std::lock_guard<std::mutex> lk(err_mu);
         err = tls_error();
         return code;
     }
     int planes() const { return mix == JSG_MIX_PER_CHANNEL ? channels : 1; }
+    void publish() {
+        a_W.store(W); a_H.store(H); a_n.store(n); a_channels.store(channels); a_hop.store(hop);
+        a_feedblocks.store(feedblocks); a_fs.store(fs);
+    }
 };
 
 #define JSG_HIP(e, call)                                   \
@@ -135,7 +184,7 @@ int rebuild_plan(jsg_engine* e) {
         e->plan = nullptr;
     }
     const int rc = jsg_plan_create(&e->plan, e->n, e->window.data(), e->power_scale);
-    if (rc != JSG_OK) e->err = tls_error();
+    if (rc != JSG_OK) return e->fail_tls(rc);
     return rc;
 }
 
@@ -146,6 +195,13 @@ int build_window(jsg_engine* e) {   // Spectrogram::setWindowFkt
     const int rc = jsg_window_build(e->window_choice, e->n, e->window.data());
     if (rc != JSG_OK) return e->fail(rc, "jsg_window_build failed");
     return rebuild_plan(e);
+}
+
+// both streams idle (setters; they hold rd_mu and mu)
+int quiesce(jsg_engine* e) {
+    JSG_HIP(e, hipStreamSynchronize(e->stream));
+    JSG_HIP(e, hipStreamSynchronize(e->rstream));
+    return JSG_OK;
 }
 
 int ensure_input_capacity(jsg_engine* e, int blocks, bool keep_tail) {
@@ -168,6 +224,7 @@ int ensure_input_capacity(jsg_engine* e, int blocks, bool keep_tail) {
 }
 
 // Spectrogram::buildmem (Spectrogram.cpp:213-238): geometry, -120 dB ring, zeroed input ring, counters.
+// Called with rd_mu and mu held.
 int buildmem(jsg_engine* e) {
     JSG_HIP(e, hipSetDevice(e->device));
     e->hop = jsg_feed_samples(e->feed_percent, e->n);
@@ -177,7 +234,9 @@ int buildmem(jsg_engine* e) {
     e->H = e->n / 2 + 1;
     e->pitch = round_up(e->H, 32);
     const size_t need = size_t(e->W) * size_t(e->pitch) * size_t(e->planes());
-    JSG_HIP(e, hipStreamSynchronize(e->stream));
+    int rc = quiesce(e);
+    if (rc != JSG_OK) return rc;
+    ++e->generation;
     if (need != e->ring_floats) {
         if (e->d_ring) (void)hipFree(e->d_ring);
         e->d_ring = nullptr;
@@ -188,11 +247,12 @@ int buildmem(jsg_engine* e) {
     uint32_t bits;
     std::memcpy(&bits, &kRingFillDb, 4);
     JSG_HIP(e, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_ring), int(bits), need, e->stream));
-    // input ring: drop and re-create zeroed (channel count or fft size may have changed)
+    // input ring: drop and re-create zeroed (channel count or fft size may have changed); one block of capacity is
+    // always there, so jsg_process_block never allocates
     if (e->d_in) (void)hipFree(e->d_in);
     e->d_in = nullptr;
     e->in_cap_blocks = 0;
-    int rc = ensure_input_capacity(e, 1, false);
+    rc = ensure_input_capacity(e, 1, false);
     if (rc != JSG_OK) return rc;
     const size_t slot = size_t(e->channels) * size_t(e->n);
     if (slot != e->pin_slot_floats) {
@@ -206,6 +266,8 @@ int buildmem(jsg_engine* e) {
         if (!e->pin_done[i]) JSG_HIP(e, hipEventCreateWithFlags(&e->pin_done[i], hipEventDisableTiming));
     e->mem_counter = 0;
     e->new_entry = kNewEntrySentinel;
+    e->host_fixed_valid = false;
+    e->publish();
     return JSG_OK;
 }
 
@@ -213,7 +275,8 @@ int upload_lut(jsg_engine* e) {
     e->lut.assign(size_t(e->n_colors), 0);
     int rc = jsg_colormap_build(e->n_colors, e->scheme, e->lut.data());
     if (rc != JSG_OK) return e->fail(rc, "jsg_colormap_build failed");
-    JSG_HIP(e, hipStreamSynchronize(e->stream));
+    rc = quiesce(e);
+    if (rc != JSG_OK) return rc;
     if (e->d_lut) (void)hipFree(e->d_lut);
     e->d_lut = nullptr;
     JSG_HIP(e, hipMalloc(reinterpret_cast<void**>(&e->d_lut), size_t(e->n_colors) * 4));
@@ -221,7 +284,7 @@ int upload_lut(jsg_engine* e) {
     return JSG_OK;
 }
 
-// frames of `blocks` new blocks whose samples already sit behind the tail in d_in
+// frames of `blocks` new blocks whose samples already sit behind the tail in d_in (mu held; enqueues only)
 int run_blocks(jsg_engine* e, int blocks) {
     const long long frames = (long long)blocks * e->feedblocks;
     if (!e->pause && frames > 0) {   // paused: the reference computes and drops the columns (Spectrogram.cpp:111)
@@ -230,6 +293,7 @@ int run_blocks(jsg_engine* e, int blocks) {
         jsg_stft_args a{};
         a.in = e->d_in;
         a.in_pitch = e->in_pitch;
+        a.in_samples = int64_t(blocks + 1) * e->n;
         a.channels = e->channels;
         a.hop = e->hop;
         a.feedblocks = e->feedblocks;
@@ -242,10 +306,7 @@ int run_blocks(jsg_engine* e, int blocks) {
         a.ring_width = e->W;
         a.ring_pos = int((e->mem_counter + skip) % e->W);
         const int rc = jsg_stft_db_launch(e->plan, &a, e->stream);
-        if (rc != JSG_OK) {
-            e->err = tls_error();
-            return rc;
-        }
+        if (rc != JSG_OK) return e->fail_tls(rc);
         e->mem_counter = int((e->mem_counter + frames) % e->W);
         e->new_entry += frames;
         if (e->new_entry > 2000000000ll) e->new_entry = 2000000000ll;   // the reference's int would overflow
@@ -256,32 +317,53 @@ int run_blocks(jsg_engine* e, int blocks) {
     return JSG_OK;
 }
 
-}  // namespace
+// Reader protocol, part 1 (mu held): everything produced so far becomes visible to rstream.
+int reader_begin(jsg_engine* e) {
+    JSG_HIP(e, hipEventRecord(e->ev_ring, e->stream));
+    JSG_HIP(e, hipStreamWaitEvent(e->rstream, e->ev_ring, 0));
+    return JSG_OK;
+}
+// Reader protocol, part 2 (mu held, after the ring reads were enqueued on rstream): later kernels wait for them.
+int reader_end(jsg_engine* e) {
+    JSG_HIP(e, hipEventRecord(e->ev_read, e->rstream));
+    JSG_HIP(e, hipStreamWaitEvent(e->stream, e->ev_read, 0));
+    return JSG_OK;
+}
 
-extern "C" {
-
-const char* jsg_last_error(const jsg_engine* e) { return e ? e->err.c_str() : tls_error().c_str(); }
-
-int jsg_create(jsg_engine** out, int channels) {
+int create_on(jsg_engine** out, int channels, int device) {
     if (!out || channels <= 0) return jsg_fail(JSG_ERR_INVALID, "jsg_create: bad argument");
     *out = nullptr;
     int ndev = 0;
     hipError_t herr = hipGetDeviceCount(&ndev);
     if (herr != hipSuccess || ndev <= 0)
         return jsg_fail(JSG_ERR_NO_DEVICE, "jsg_create: no HIP device available (this engine has no CPU fallback)");
+    if (device >= ndev) return jsg_fail(JSG_ERR_NO_DEVICE, "jsg_create_on_device: no such device");
     jsg_engine* e = new (std::nothrow) jsg_engine();
     if (!e) return jsg_fail(JSG_ERR_NOMEM, "jsg_create: out of memory");
     e->channels = channels;
-    herr = hipGetDevice(&e->device);
+    if (device < 0) herr = hipGetDevice(&e->device);
+    else {
+        e->device = device;
+        herr = hipSetDevice(device);
+    }
     if (herr == hipSuccess) herr = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (herr == hipSuccess) herr = hipStreamCreateWithFlags(&e->rstream, hipStreamNonBlocking);
+    if (herr == hipSuccess) herr = hipEventCreateWithFlags(&e->ev_ring, hipEventDisableTiming);
+    if (herr == hipSuccess) herr = hipEventCreateWithFlags(&e->ev_read, hipEventDisableTiming);
+    if (herr == hipSuccess) herr = hipEventCreateWithFlags(&e->ev_host, hipEventDisableTiming);
     if (herr != hipSuccess) {
         const int code = jsg_fail_hip(herr, "jsg_create");
-        delete e;
+        jsg_destroy(e);
         return code;
     }
-    int rc = buildmem(e);
-    if (rc == JSG_OK) rc = build_window(e);   // (the reference leaves m_window empty until setFFTSize/setWindow)
-    if (rc == JSG_OK) rc = upload_lut(e);
+    int rc;
+    {
+        std::lock_guard<std::mutex> rlk(e->rd_mu);
+        std::lock_guard<std::mutex> lk(e->mu);
+        rc = buildmem(e);
+        if (rc == JSG_OK) rc = build_window(e);   // (the reference leaves m_window empty until setFFTSize/setWindow)
+        if (rc == JSG_OK) rc = upload_lut(e);
+    }
     if (rc != JSG_OK) {
         tls_error() = e->err;
         jsg_destroy(e);
@@ -291,23 +373,53 @@ int jsg_create(jsg_engine** out, int channels) {
     return JSG_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+const char* jsg_last_error(const jsg_engine* e) {
+    if (!e) return tls_error().c_str();
+    static thread_local std::string copy;   // the engine's text may be rewritten by another thread: hand out a private copy
+    jsg_engine* m = const_cast<jsg_engine*>(e);
+    std::lock_guard<std::mutex> lk(m->err_mu);
+    copy = m->err;
+    return copy.c_str();
+}
+
+int jsg_create(jsg_engine** out, int channels) { return create_on(out, channels, -1); }
+
+int jsg_create_on_device(jsg_engine** out, int channels, int device) {
+    if (device < 0) return jsg_fail(JSG_ERR_INVALID, "jsg_create_on_device: negative device index");
+    return create_on(out, channels, device);
+}
+
+int jsg_get_device(const jsg_engine* e) { return e ? e->device : JSG_ERR_INVALID; }
+
 int jsg_destroy(jsg_engine* e) {
     if (!e) return JSG_OK;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->rstream) (void)hipStreamSynchronize(e->rstream);
     if (e->plan) jsg_plan_destroy(e->plan);
     if (e->d_ring) (void)hipFree(e->d_ring);
     if (e->d_in) (void)hipFree(e->d_in);
     if (e->d_lut) (void)hipFree(e->d_lut);
     if (e->d_img) (void)hipFree(e->d_img);
     if (e->h_pin) (void)hipHostFree(e->h_pin);
+    if (e->h_mem) (void)hipHostFree(e->h_mem);
+    if (e->d_snap) (void)hipFree(e->d_snap);
+    if (e->ev_host) (void)hipEventDestroy(e->ev_host);
     for (int i = 0; i < jsg_engine::kPinSlots; ++i)
         if (e->pin_done[i]) (void)hipEventDestroy(e->pin_done[i]);
+    if (e->ev_ring) (void)hipEventDestroy(e->ev_ring);
+    if (e->ev_read) (void)hipEventDestroy(e->ev_read);
     if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->rstream) (void)hipStreamDestroy(e->rstream);
     delete e;
     return JSG_OK;
 }
 
+// producer / short sections: the state lock only
 #define JSG_LOCK(e)                                                          \
     if (!(e)) return jsg_fail(JSG_ERR_INVALID, "null engine");               \
     std::lock_guard<std::mutex> _lk((e)->mu);                                \
@@ -316,22 +428,32 @@ int jsg_destroy(jsg_engine* e) {
         if (_e != hipSuccess) return (e)->fail_hip(_e, "hipSetDevice");      \
     } while (0)
 
+// setters: exclude the readers as well (they may free what a reader is still copying from)
+#define JSG_LOCK_CONFIG(e)                                                   \
+    if (!(e)) return jsg_fail(JSG_ERR_INVALID, "null engine");               \
+    std::lock_guard<std::mutex> _rlk((e)->rd_mu);                            \
+    std::lock_guard<std::mutex> _lk((e)->mu);                                \
+    do {                                                                     \
+        hipError_t _e = hipSetDevice((e)->device);                           \
+        if (_e != hipSuccess) return (e)->fail_hip(_e, "hipSetDevice");      \
+    } while (0)
+
 int jsg_set_samplerate(jsg_engine* e, float fs) {
-    JSG_LOCK(e);
+    JSG_LOCK_CONFIG(e);
     if (!(fs > 0.f)) return e->fail(JSG_ERR_INVALID, "sample rate must be positive");
     e->fs = fs;
     return buildmem(e);
 }
 
 int jsg_set_channels(jsg_engine* e, int channels) {
-    JSG_LOCK(e);
+    JSG_LOCK_CONFIG(e);
     if (channels <= 0) return e->fail(JSG_ERR_INVALID, "channel count must be positive");
     e->channels = channels;
     return buildmem(e);
 }
 
 int jsg_set_fft_size(jsg_engine* e, int n) {
-    JSG_LOCK(e);
+    JSG_LOCK_CONFIG(e);
     if (n != 512 && n != 1024 && n != 2048 && n != 4096 && n != 8192)
         return e->fail(JSG_ERR_UNSUPPORTED, "FFT size must be 512, 1024, 2048, 4096 or 8192");
     e->n = n;
@@ -344,19 +466,19 @@ int jsg_set_fft_size(jsg_engine* e, int n) {
 
 int jsg_set_closest_fft_size_ms(jsg_engine* e, float ms) {
     if (!e) return jsg_fail(JSG_ERR_INVALID, "null engine");
-    const int n = jsg_next_power_of_2(ms, e->fs);
+    const int n = jsg_next_power_of_2(ms, e->a_fs.load());
     return jsg_set_fft_size(e, n);
 }
 
 int jsg_set_memory_time_s(jsg_engine* e, float seconds) {
-    JSG_LOCK(e);
+    JSG_LOCK_CONFIG(e);
     if (!(seconds > 0.f)) return e->fail(JSG_ERR_INVALID, "memory time must be positive");
     e->memsize_s = seconds;
     return buildmem(e);
 }
 
 int jsg_set_feed_percent(jsg_engine* e, int feed) {
-    JSG_LOCK(e);
+    JSG_LOCK_CONFIG(e);
     switch (feed) {   // Spectrogram.cpp:191-209
         case JSG_FEED_100: e->feed_percent = 100.f; e->feedblocks = 1; break;
         case JSG_FEED_50: e->feed_percent = 50.f; e->feedblocks = 2; break;
@@ -368,7 +490,7 @@ int jsg_set_feed_percent(jsg_engine* e, int feed) {
 }
 
 int jsg_set_feed_percent_ext(jsg_engine* e, float percent) {
-    JSG_LOCK(e);
+    JSG_LOCK_CONFIG(e);
     const int hop = jsg_feed_samples(percent, e->n);
     if (hop <= 0 || hop > e->n) return e->fail(JSG_ERR_INVALID, "feed percentage out of range");
     e->feed_percent = percent;
@@ -383,7 +505,7 @@ int jsg_set_pause_mode(jsg_engine* e, int paused) {
 }
 
 int jsg_set_window(jsg_engine* e, int window) {
-    JSG_LOCK(e);
+    JSG_LOCK_CONFIG(e);
     if (window < JSG_WIN_RECT || window > JSG_WIN_HANNPOISSON) return e->fail(JSG_ERR_INVALID, "unknown window");
     e->window_choice = window;
     e->window_custom = false;
@@ -392,7 +514,7 @@ int jsg_set_window(jsg_engine* e, int window) {
 }
 
 int jsg_set_window_table(jsg_engine* e, const float* w, int n) {
-    JSG_LOCK(e);
+    JSG_LOCK_CONFIG(e);
     if (!w || n != e->n) return e->fail(JSG_ERR_SIZE_MISMATCH, "window table must have fft-size entries");
     e->window.assign(w, w + n);
     e->window_custom = true;
@@ -401,7 +523,7 @@ int jsg_set_window_table(jsg_engine* e, const float* w, int n) {
 }
 
 int jsg_set_mix_mode(jsg_engine* e, int mode) {
-    JSG_LOCK(e);
+    JSG_LOCK_CONFIG(e);
     const bool known = (mode >= JSG_MIX_ABSMEAN && mode <= JSG_MIX_RIGHT) || mode == JSG_MIX_PER_CHANNEL;
     if (!known) return e->fail(JSG_ERR_INVALID, "unknown mix mode");
     if (mode == JSG_MIX_RIGHT && e->channels < 2) return e->fail(JSG_ERR_INVALID, "JSG_MIX_RIGHT needs two channels");
@@ -411,45 +533,61 @@ int jsg_set_mix_mode(jsg_engine* e, int mode) {
 }
 
 int jsg_set_power_scale(jsg_engine* e, float scale) {
-    JSG_LOCK(e);
+    JSG_LOCK_CONFIG(e);
     if (!(scale > 0.f)) return e->fail(JSG_ERR_INVALID, "power scale must be positive");
     e->power_scale = scale;
     JSG_HIP(e, hipStreamSynchronize(e->stream));
     return rebuild_plan(e);
 }
 
-int jsg_get_spectrum_size(const jsg_engine* e) { return e ? e->H : JSG_ERR_INVALID; }
-int jsg_get_memory_size(const jsg_engine* e) { return e ? e->W : JSG_ERR_INVALID; }
-float jsg_get_samplerate(const jsg_engine* e) { return e ? e->fs : 0.f; }
-int jsg_get_fft_size(const jsg_engine* e) { return e ? e->n : JSG_ERR_INVALID; }
-int jsg_get_feed_samples(const jsg_engine* e) { return e ? e->hop : JSG_ERR_INVALID; }
-int jsg_get_feedblocks(const jsg_engine* e) { return e ? e->feedblocks : JSG_ERR_INVALID; }
-int jsg_get_channels(const jsg_engine* e) { return e ? e->channels : JSG_ERR_INVALID; }
+// lock-free getters (the GUI polls them while the audio thread runs)
+int jsg_get_spectrum_size(const jsg_engine* e) { return e ? e->a_H.load() : JSG_ERR_INVALID; }
+int jsg_get_memory_size(const jsg_engine* e) { return e ? e->a_W.load() : JSG_ERR_INVALID; }
+float jsg_get_samplerate(const jsg_engine* e) { return e ? e->a_fs.load() : 0.f; }
+int jsg_get_fft_size(const jsg_engine* e) { return e ? e->a_n.load() : JSG_ERR_INVALID; }
+int jsg_get_feed_samples(const jsg_engine* e) { return e ? e->a_hop.load() : JSG_ERR_INVALID; }
+int jsg_get_feedblocks(const jsg_engine* e) { return e ? e->a_feedblocks.load() : JSG_ERR_INVALID; }
+int jsg_get_channels(const jsg_engine* e) { return e ? e->a_channels.load() : JSG_ERR_INVALID; }
 
-int jsg_get_window(const jsg_engine* e, float* out, int n) {
+int jsg_get_window(const jsg_engine* ce, float* out, int n) {
+    jsg_engine* e = const_cast<jsg_engine*>(ce);
     if (!e || !out) return jsg_fail(JSG_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(e->mu);
     if (n != int(e->window.size())) return jsg_fail(JSG_ERR_SIZE_MISMATCH, "window size mismatch");
     std::memcpy(out, e->window.data(), size_t(n) * sizeof(float));
     return JSG_OK;
 }
 
 int jsg_process_block(jsg_engine* e, const float* const* planar) {
-    JSG_LOCK(e);
+    if (!e) return jsg_fail(JSG_ERR_INVALID, "null engine");
     if (!planar) return e->fail(JSG_ERR_INVALID, "null block");
-    int rc = ensure_input_capacity(e, 1, true);
-    if (rc != JSG_OK) return rc;
-    // copy-in (reference Spectrogram.cpp:41-48) through the pinned ring: host memcpy now, DMA later
-    const unsigned slot = e->pin_next++ % jsg_engine::kPinSlots;
-    JSG_HIP(e, hipEventSynchronize(e->pin_done[slot]));   // only waits if the GPU is 8 blocks behind
-    float* stage = e->h_pin + size_t(slot) * e->pin_slot_floats;
-    for (int c = 0; c < e->channels; ++c) {
-        if (!planar[c]) return e->fail(JSG_ERR_INVALID, "null channel pointer");
-        std::memcpy(stage + size_t(c) * e->n, planar[c], size_t(e->n) * sizeof(float));
+    for (;;) {
+        std::unique_lock<std::mutex> lk(e->mu);
+        hipError_t herr = hipSetDevice(e->device);
+        if (herr != hipSuccess) return e->fail_hip(herr, "hipSetDevice");
+        // copy-in (reference Spectrogram.cpp:41-48) through the pinned ring: host memcpy now, DMA later
+        const unsigned slot = e->pin_next % jsg_engine::kPinSlots;
+        if (hipEventQuery(e->pin_done[slot]) != hipSuccess) {
+            // the GPU is 8 blocks behind: wait for the slot WITHOUT the lock, then start over (a setter may have run)
+            hipEvent_t ev = e->pin_done[slot];
+            const unsigned long long gen = e->generation;
+            lk.unlock();
+            herr = hipEventSynchronize(ev);
+            if (herr != hipSuccess) return e->fail_hip(herr, "hipEventSynchronize");
+            (void)gen;
+            continue;
+        }
+        ++e->pin_next;
+        float* stage = e->h_pin + size_t(slot) * e->pin_slot_floats;
+        for (int c = 0; c < e->channels; ++c) {
+            if (!planar[c]) return e->fail(JSG_ERR_INVALID, "null channel pointer");
+            std::memcpy(stage + size_t(c) * e->n, planar[c], size_t(e->n) * sizeof(float));
+        }
+        JSG_HIP(e, hipMemcpy2DAsync(e->d_in + e->n, size_t(e->in_pitch) * 4, stage, size_t(e->n) * 4, size_t(e->n) * 4,
+                                    size_t(e->channels), hipMemcpyHostToDevice, e->stream));
+        JSG_HIP(e, hipEventRecord(e->pin_done[slot], e->stream));
+        return run_blocks(e, 1);
     }
-    JSG_HIP(e, hipMemcpy2DAsync(e->d_in + e->n, size_t(e->in_pitch) * 4, stage, size_t(e->n) * 4, size_t(e->n) * 4,
-                                size_t(e->channels), hipMemcpyHostToDevice, e->stream));
-    JSG_HIP(e, hipEventRecord(e->pin_done[slot], e->stream));
-    return run_blocks(e, 1);
 }
 
 int jsg_process_blocks(jsg_engine* e, const float* samples, int64_t pitch, int n_blocks) {
@@ -474,37 +612,114 @@ int jsg_process_blocks_device(jsg_engine* e, const float* d_samples, int64_t pit
     return run_blocks(e, n_blocks);
 }
 
-int jsg_get_mem(jsg_engine* e, float* dst, int dst_columns, int* pos) {
-    JSG_LOCK(e);
+namespace {
+
+// Spectrogram::getMem (Spectrogram.cpp:295-331).  The new columns (or all of them) travel ring -> page-locked h_mem on
+// rstream; the caller's buffer is filled from h_mem after the copy has completed, outside the state lock.
+// dst_dense: [planes*W][H] floats, or rows: planes*W pointers to H floats each (vector<vector<float>> of the host class).
+int get_mem_impl(jsg_engine* e, float* dst_dense, float* const* rows, int dst_columns, int* pos, bool peek = false) {
+    if (!e) return jsg_fail(JSG_ERR_INVALID, "null engine");
+    std::lock_guard<std::mutex> rlk(e->rd_mu);
+    // Geometry cannot change while rd_mu is held (every setter takes it first), so the reader's own buffers are
+    // (re)allocated here, OUTSIDE the state lock: page-locking 15 MB takes milliseconds and must not stall the producer.
+    hipError_t herr = hipSetDevice(e->device);
+    if (herr != hipSuccess) return e->fail_hip(herr, "hipSetDevice");
     const int planes = e->planes();
-    if (!dst || dst_columns != e->W * planes) return e->fail(JSG_ERR_SIZE_MISMATCH, "getMem: buffer size mismatch");
     const int W = e->W, H = e->H;
-    auto copy_cols = [&](int first, int count) -> hipError_t {
-        if (count <= 0) return hipSuccess;
-        for (int p = 0; p < planes; ++p) {
-            hipError_t r = hipMemcpy2DAsync(dst + (size_t(p) * W + first) * H, size_t(H) * 4,
-                                            e->d_ring + (size_t(p) * W + first) * e->pitch, size_t(e->pitch) * 4,
-                                            size_t(H) * 4, size_t(count), hipMemcpyDeviceToHost, e->stream);
-            if (r != hipSuccess) return r;
-        }
-        return hipSuccess;
-    };
-    const long long nec = e->new_entry;
-    if (nec >= W) {                                   // Spectrogram.cpp:300-304
-        JSG_HIP(e, copy_cols(0, W));
-    } else {
-        const int start = e->mem_counter - int(nec);  // :307
-        if (start >= 0) {
-            JSG_HIP(e, copy_cols(start, int(nec)));   // :310-311
+    int mem_counter;
+    long long nec;
+    struct Span { int first, count; } spans[2] = {{0, 0}, {0, 0}};
+    if ((!dst_dense && !rows) || dst_columns != W * planes) return e->fail(JSG_ERR_SIZE_MISMATCH, "getMem: buffer size mismatch");
+    const size_t need = size_t(W) * size_t(H) * size_t(planes);
+    if (need > e->h_mem_floats) {   // first read after a (re)configuration
+        if (e->h_mem) (void)hipHostFree(e->h_mem);
+        e->h_mem = nullptr;
+        e->h_mem_floats = 0;
+        JSG_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_mem), need * sizeof(float), hipHostMallocDefault));
+        e->h_mem_floats = need;
+    }
+    if (e->ring_floats > e->d_snap_floats) {
+        if (e->d_snap) (void)hipFree(e->d_snap);
+        e->d_snap = nullptr;
+        e->d_snap_floats = 0;
+        JSG_HIP(e, hipMalloc(reinterpret_cast<void**>(&e->d_snap), e->ring_floats * sizeof(float)));
+        e->d_snap_floats = e->ring_floats;
+    }
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        nec = e->new_entry;
+        mem_counter = e->mem_counter;
+        if (peek || nec >= W) {                           // Spectrogram.cpp:300-304
+            spans[0] = {0, W};
         } else {
-            JSG_HIP(e, copy_cols(0, e->mem_counter));          // :315-316
-            JSG_HIP(e, copy_cols(W + start, -start));          // :318-319
+            const int start = mem_counter - int(nec);     // :307
+            if (start >= 0) {
+                spans[0] = {start, int(nec)};             // :310-311
+            } else {
+                spans[0] = {0, mem_counter};              // :315-316
+                spans[1] = {W + start, -start};           // :318-319
+            }
+        }
+        int rc = reader_begin(e);
+        if (rc != JSG_OK) return rc;
+        // 1. ring -> d_snap on the device (whole columns incl. padding: contiguous, HBM speed).  Only this holds up later kernels.
+        for (const Span& s : spans) {
+            if (s.count <= 0) continue;
+            for (int p = 0; p < planes; ++p) {
+                const size_t off = (size_t(p) * W + s.first) * size_t(e->pitch);
+                JSG_HIP(e, hipMemcpyAsync(e->d_snap + off, e->d_ring + off, size_t(s.count) * e->pitch * sizeof(float),
+                                          hipMemcpyDeviceToDevice, e->rstream));
+            }
+        }
+        rc = reader_end(e);
+        if (rc != JSG_OK) return rc;
+        // 2. d_snap -> page-locked host memory, dense [W][H]
+        for (const Span& s : spans) {
+            if (s.count <= 0) continue;
+            for (int p = 0; p < planes; ++p)
+                JSG_HIP(e, hipMemcpy2DAsync(e->h_mem + (size_t(p) * W + s.first) * H, size_t(H) * 4,
+                                            e->d_snap + (size_t(p) * W + s.first) * e->pitch, size_t(e->pitch) * 4, size_t(H) * 4,
+                                            size_t(s.count), hipMemcpyDeviceToHost, e->rstream));
+        }
+        JSG_HIP(e, hipEventRecord(e->ev_host, e->rstream));
+        if (!peek) e->new_entry = 0;                      // :328
+    }
+    JSG_HIP(e, hipEventSynchronize(e->ev_host));           // the producer is not held up by this wait
+    for (const Span& s : spans) {
+        if (s.count <= 0) continue;
+        for (int p = 0; p < planes; ++p) {
+            const float* src = e->h_mem + (size_t(p) * W + s.first) * H;
+            if (dst_dense) {
+                std::memcpy(dst_dense + (size_t(p) * W + s.first) * H, src, size_t(s.count) * H * sizeof(float));
+            } else {
+                for (int c = 0; c < s.count; ++c) {
+                    float* row = rows[size_t(p) * W + s.first + c];
+                    if (row) std::memcpy(row, src + size_t(c) * H, size_t(H) * sizeof(float));
+                }
+            }
         }
     }
-    JSG_HIP(e, hipStreamSynchronize(e->stream));
-    e->new_entry = 0;                                 // :328
-    if (pos) *pos = e->mem_counter;                   // :329
+    if (pos) *pos = mem_counter;                          // :329
     return int(nec);
+}
+
+}  // namespace
+
+int jsg_get_mem(jsg_engine* e, float* dst, int dst_columns, int* pos) {
+    if (e && !dst) return e->fail(JSG_ERR_SIZE_MISMATCH, "getMem: buffer size mismatch");
+    return get_mem_impl(e, dst, nullptr, dst_columns, pos);
+}
+
+int jsg_peek_mem(jsg_engine* e, float* dst, int dst_columns, int* pos) {
+    if (e && !dst) return e->fail(JSG_ERR_SIZE_MISMATCH, "peekMem: buffer size mismatch");
+    const int rc = get_mem_impl(e, dst, nullptr, dst_columns, pos, true);
+    return rc < 0 ? rc : int(std::min<long long>(rc, 2000000000ll));
+}
+
+int jsg_get_mem_rows(jsg_engine* e, float* const* rows, int n_rows, int row_len, int* pos) {
+    if (!e) return jsg_fail(JSG_ERR_INVALID, "null engine");
+    if (!rows || row_len != e->a_H.load()) return e->fail(JSG_ERR_SIZE_MISMATCH, "getMem: row length mismatch");
+    return get_mem_impl(e, nullptr, rows, n_rows, pos);
 }
 
 int jsg_ring_device(jsg_engine* e, float** d_ring, int64_t* pitch, int* width, int* pos) {
@@ -517,15 +732,17 @@ int jsg_ring_device(jsg_engine* e, float** d_ring, int64_t* pitch, int* width, i
 }
 
 int jsg_sync(jsg_engine* e) {
-    JSG_LOCK(e);
-    JSG_HIP(e, hipStreamSynchronize(e->stream));
+    if (!e) return jsg_fail(JSG_ERR_INVALID, "null engine");
+    hipError_t herr = hipSetDevice(e->device);
+    if (herr == hipSuccess) herr = hipStreamSynchronize(e->stream);   // no lock: the stream handle lives as long as the engine
+    if (herr != hipSuccess) return e->fail_hip(herr, "jsg_sync");
     return JSG_OK;
 }
 
 void* jsg_stream(jsg_engine* e) { return e ? reinterpret_cast<void*>(e->stream) : nullptr; }
 
 int jsg_display_set_colormap(jsg_engine* e, int n_colors, int scheme) {
-    JSG_LOCK(e);
+    JSG_LOCK_CONFIG(e);
     if (n_colors <= 0 || n_colors > 65535 || scheme < JSG_CM_MONO || scheme > JSG_CM_JADE)
         return e->fail(JSG_ERR_INVALID, "bad colour map");
     e->n_colors = n_colors;
@@ -535,78 +752,143 @@ int jsg_display_set_colormap(jsg_engine* e, int n_colors, int scheme) {
 }
 
 int jsg_display_set_running(jsg_engine* e, int running) {
-    JSG_LOCK(e);
+    JSG_LOCK_CONFIG(e);
+    if (e->running != (running != 0)) e->host_fixed_valid = false;
     e->running = running != 0;
     return JSG_OK;
 }
 
 int jsg_display_invalidate(jsg_engine* e) {
-    JSG_LOCK(e);
+    JSG_LOCK_CONFIG(e);
     e->recompute_all = true;
     return JSG_OK;
 }
 
-int jsg_display_update(jsg_engine* e, float min_color, float max_color, uint32_t* argb, int64_t pitch, int* new_vals,
-                       int* pos_out) {
-    JSG_LOCK(e);
-    if (e->mix == JSG_MIX_PER_CHANNEL) return e->fail(JSG_ERR_UNSUPPORTED, "display needs a mixed (single) spectrogram");
-    const int W = e->W, H = e->H;
-    if (!argb || pitch < W) return e->fail(JSG_ERR_INVALID, "bad image buffer");
-    if (W != e->img_w || H != e->img_h) {             // Spectrogram.cpp:595-605
-        JSG_HIP(e, hipStreamSynchronize(e->stream));
+namespace {
+
+struct Tick {   // what a display tick decided under the state lock
+    int W = 0, H = 0, pos = 0, n_cols = 0, col_first = 0;
+    long long nec = 0;
+    bool all = false;
+};
+
+// (rd_mu held by the caller) snapshot + colour kernel on rstream; returns with the image columns of this tick coloured in
+// d_img as far as the GPU queue is concerned.  The state lock is released before anything is copied to the host.
+int display_enqueue(jsg_engine* e, float min_color, float max_color, bool tile_mode, int max_cols, Tick* t, int* need_full) {
+    hipError_t herr = hipSetDevice(e->device);
+    if (herr != hipSuccess) return e->fail_hip(herr, "hipSetDevice");
+    if (!tile_mode && (e->W != e->img_w || e->H != e->img_h)) {   // Spectrogram.cpp:595-605; geometry is stable under rd_mu,
+        JSG_HIP(e, hipStreamSynchronize(e->rstream));             // and the image belongs to the readers: no state lock here
         if (e->d_img) (void)hipFree(e->d_img);
         e->d_img = nullptr;
-        e->img_pitch = round_up(W, 32);
-        JSG_HIP(e, hipMalloc(reinterpret_cast<void**>(&e->d_img), size_t(e->img_pitch) * H * 4));
-        e->img_w = W;
-        e->img_h = H;
+        e->img_pitch = round_up(e->W, 32);
+        JSG_HIP(e, hipMalloc(reinterpret_cast<void**>(&e->d_img), size_t(e->img_pitch) * e->H * 4));
+        e->img_w = e->W;
+        e->img_h = e->H;
         e->recompute_all = true;
     }
-    const long long nec = e->new_entry;               // getMem, Spectrogram.cpp:607-608
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->mix == JSG_MIX_PER_CHANNEL) return e->fail(JSG_ERR_UNSUPPORTED, "display needs a mixed (single) spectrogram");
+    const int W = e->W, H = e->H;
+    t->W = W;
+    t->H = H;
+    const long long nec = e->new_entry;                   // getMem, Spectrogram.cpp:607-608
+    if (tile_mode) {
+        if (e->recompute_all || W != e->img_w || H != e->img_h || nec > W || nec > max_cols) {
+            t->nec = std::min<long long>(nec, 2000000000ll);
+            t->pos = e->mem_counter;
+            *need_full = 1;
+            return JSG_OK;
+        }
+    }
     e->new_entry = 0;
-    const int pos = e->mem_counter;
-    if (nec > W) e->recompute_all = true;             // :610-613
-    jsg_colormap_args a{};
-    a.db = e->d_ring;
-    a.db_pitch = e->pitch;
-    a.ring_width = W;
-    a.height = H;
-    a.x_wrap = W;
-    a.lut = e->d_lut;
-    a.n_colors = e->n_colors;
-    jsg_colormap_range(e->n_colors, min_color, max_color, &a.vmin, &a.vmax, &a.access_mult);   // :617
-    a.argb_out = e->d_img;
-    a.argb_pitch = e->img_pitch;
-    const bool all = e->recompute_all;
-    if (all) {                                        // :623-657
+    t->nec = nec;
+    t->pos = e->mem_counter;
+    if (nec > W) e->recompute_all = true;                 // :610-613
+    t->all = !tile_mode && e->recompute_all;
+    if (t->all) {                                         // :623-657
         e->recompute_all = false;
-        a.col_first = 0;
-        a.n_cols = W;
-    } else {                                          // :658-724 (only the new columns)
-        a.n_cols = int(std::min<long long>(nec, W));
-        a.col_first = ((pos - a.n_cols) % W + W) % W;
+        t->col_first = 0;
+        t->n_cols = W;
+    } else {                                              // :658-724 (only the new columns)
+        t->n_cols = int(std::min<long long>(nec, W));
+        t->col_first = ((t->pos - t->n_cols) % W + W) % W;
     }
-    a.x_first = a.col_first;
-    int rc = jsg_colormap_launch(&a, e->stream);
-    if (rc != JSG_OK) {
-        e->err = tls_error();
-        return rc;
+    if (t->n_cols > 0) {
+        jsg_colormap_args a{};
+        a.db = e->d_ring;
+        a.db_pitch = e->pitch;
+        a.ring_width = W;
+        a.height = H;
+        a.x_wrap = W;
+        a.lut = e->d_lut;
+        a.n_colors = e->n_colors;
+        jsg_colormap_range(e->n_colors, min_color, max_color, &a.vmin, &a.vmax, &a.access_mult);   // :617
+        a.argb_out = e->d_img;
+        a.argb_pitch = e->img_pitch;
+        a.col_first = t->col_first;
+        a.n_cols = t->n_cols;
+        a.x_first = t->col_first;
+        int rc = reader_begin(e);
+        if (rc != JSG_OK) return rc;
+        rc = jsg_colormap_launch(&a, e->rstream);
+        if (rc != JSG_OK) return e->fail_tls(rc);
+        rc = reader_end(e);                               // the ring is free again once the colour kernel has run
+        if (rc != JSG_OK) return rc;
     }
+    return JSG_OK;
+}
+
+// copy image columns [first, first+count) (ring order, no wrap) to host x = x0.. of `argb`
+hipError_t copy_cols(jsg_engine* e, uint32_t* argb, int64_t pitch, int x0, int first, int count) {
+    if (count <= 0) return hipSuccess;
+    return hipMemcpy2DAsync(argb + x0, size_t(pitch) * 4, e->d_img + first, size_t(e->img_pitch) * 4, size_t(count) * 4, size_t(e->img_h),
+                            hipMemcpyDeviceToHost, e->rstream);
+}
+
+}  // namespace
+
+int jsg_display_update(jsg_engine* e, float min_color, float max_color, uint32_t* argb, int64_t pitch, int* new_vals,
+                       int* pos_out) {
+    if (!e) return jsg_fail(JSG_ERR_INVALID, "null engine");
+    std::lock_guard<std::mutex> rlk(e->rd_mu);
+    if (!argb || pitch < e->a_W.load()) return e->fail(JSG_ERR_INVALID, "bad image buffer");
+    Tick t;
+    int dummy = 0;
+    int rc = display_enqueue(e, min_color, max_color, false, 0, &t, &dummy);
+    if (rc != JSG_OK) return rc;
+    const int W = t.W, H = t.H, pos = t.pos;
+    if (pitch < W) return e->fail(JSG_ERR_INVALID, "bad image buffer");
     if (e->running) {
-        // x = (col + W - pos) mod W  (Spectrogram.cpp:626-631): columns [pos,W) first, then [0,pos)
-        JSG_HIP(e, hipMemcpy2DAsync(argb, size_t(pitch) * 4, e->d_img + pos, size_t(e->img_pitch) * 4, size_t(W - pos) * 4, size_t(H),
-                                    hipMemcpyDeviceToHost, e->stream));
-        if (pos > 0)
-            JSG_HIP(e, hipMemcpy2DAsync(argb + (W - pos), size_t(pitch) * 4, e->d_img, size_t(e->img_pitch) * 4, size_t(pos) * 4,
-                                        size_t(H), hipMemcpyDeviceToHost, e->stream));
-        JSG_HIP(e, hipStreamSynchronize(e->stream));
+        // x = (col + W - pos) mod W  (Spectrogram.cpp:626-631): columns [pos,W) first, then [0,pos).  Every pixel moves
+        // with every new column, so the whole image is copied (hosts that scroll their own image: jsg_display_update_tile).
+        JSG_HIP(e, copy_cols(e, argb, pitch, 0, pos, W - pos));
+        JSG_HIP(e, copy_cols(e, argb, pitch, W - pos, 0, pos));
+        JSG_HIP(e, hipStreamSynchronize(e->rstream));
+        e->host_fixed_valid = false;
     } else {
-        JSG_HIP(e, hipMemcpy2DAsync(argb, size_t(pitch) * 4, e->d_img, size_t(e->img_pitch) * 4, size_t(W) * 4, size_t(H),
-                                    hipMemcpyDeviceToHost, e->stream));
-        JSG_HIP(e, hipStreamSynchronize(e->stream));
+        // fixed display: x = column.  When the caller's image still holds the previous tick, only the columns that changed
+        // are copied: the new ones and those under the previous cursor.
+        const bool incremental = !t.all && e->host_fixed_valid && e->host_img == argb && e->host_pitch == pitch;
+        if (!incremental) {
+            JSG_HIP(e, copy_cols(e, argb, pitch, 0, 0, W));
+        } else {
+            auto copy_range = [&](int first, int count) -> hipError_t {   // ring columns [first, first+count) with wrap
+                if (count <= 0) return hipSuccess;
+                if (count >= W) return copy_cols(e, argb, pitch, 0, 0, W);
+                first = (first % W + W) % W;
+                const int n1 = std::min(count, W - first);
+                hipError_t r = copy_cols(e, argb, pitch, first, first, n1);
+                if (r == hipSuccess && count > n1) r = copy_cols(e, argb, pitch, 0, 0, count - n1);
+                return r;
+            };
+            JSG_HIP(e, copy_range(t.col_first, t.n_cols));
+            JSG_HIP(e, copy_range(e->host_cursor_pos, e->host_cursor_w));
+        }
+        JSG_HIP(e, hipStreamSynchronize(e->rstream));
         // red cursor (Spectrogram.cpp:650-656 one column after a full recolour, :703-720 otherwise)
         int drawwidth = 1;
-        if (!all) {
+        if (!t.all) {
             if (H < 2048) drawwidth++;
             if (H < 1024) drawwidth += 2;
         }
@@ -616,58 +898,38 @@ int jsg_display_update(jsg_engine* e, float min_color, float max_color, uint32_t
             if (drawpos >= W) continue;   // the reference would write outside the image here
             for (int y = 0; y < H; ++y) argb[size_t(y) * pitch + drawpos] = kJuceRed;
         }
+        e->host_img = argb;
+        e->host_pitch = pitch;
+        e->host_fixed_valid = true;
+        e->host_cursor_pos = pos;
+        e->host_cursor_w = drawwidth;
     }
-    if (new_vals) *new_vals = int(nec);
+    if (new_vals) *new_vals = int(t.nec);
     if (pos_out) *pos_out = pos;
     return JSG_OK;
 }
 
 int jsg_display_update_tile(jsg_engine* e, float min_color, float max_color, uint32_t* tile, int64_t tile_pitch,
                             int max_cols, int* new_vals, int* pos_out) {
-    JSG_LOCK(e);
-    if (e->mix == JSG_MIX_PER_CHANNEL) return e->fail(JSG_ERR_UNSUPPORTED, "display needs a mixed (single) spectrogram");
-    const int W = e->W, H = e->H;
+    if (!e) return jsg_fail(JSG_ERR_INVALID, "null engine");
+    std::lock_guard<std::mutex> rlk(e->rd_mu);
     if (!tile || max_cols <= 0 || tile_pitch < max_cols) return e->fail(JSG_ERR_INVALID, "bad tile buffer");
-    const long long nec = e->new_entry;
-    if (e->recompute_all || W != e->img_w || H != e->img_h || nec > W || nec > max_cols) {
-        if (new_vals) *new_vals = int(std::min<long long>(nec, 2000000000ll));
-        if (pos_out) *pos_out = e->mem_counter;
-        return 1;   // the caller needs the whole image: jsg_display_update
-    }
-    e->new_entry = 0;
-    const int pos = e->mem_counter;
-    const int nv = int(nec);
+    Tick t;
+    int need_full = 0;
+    int rc = display_enqueue(e, min_color, max_color, true, max_cols, &t, &need_full);
+    if (rc != JSG_OK) return rc;
+    if (new_vals) *new_vals = int(t.nec);
+    if (pos_out) *pos_out = t.pos;
+    if (need_full) return 1;   // the caller needs the whole image: jsg_display_update
+    const int nv = t.n_cols, W = t.W;
     if (nv > 0) {
-        jsg_colormap_args a{};
-        a.db = e->d_ring;
-        a.db_pitch = e->pitch;
-        a.ring_width = W;
-        a.height = H;
-        a.x_wrap = W;
-        a.lut = e->d_lut;
-        a.n_colors = e->n_colors;
-        jsg_colormap_range(e->n_colors, min_color, max_color, &a.vmin, &a.vmax, &a.access_mult);
-        a.argb_out = e->d_img;
-        a.argb_pitch = e->img_pitch;
-        a.n_cols = nv;
-        a.col_first = ((pos - nv) % W + W) % W;
-        a.x_first = a.col_first;
-        const int rc = jsg_colormap_launch(&a, e->stream);
-        if (rc != JSG_OK) {
-            e->err = tls_error();
-            return rc;
-        }
-        const int first = a.col_first;
+        const int first = t.col_first;
         const int n1 = std::min(nv, W - first);   // columns before the ring wraps
-        JSG_HIP(e, hipMemcpy2DAsync(tile, size_t(tile_pitch) * 4, e->d_img + first, size_t(e->img_pitch) * 4, size_t(n1) * 4, size_t(H),
-                                    hipMemcpyDeviceToHost, e->stream));
-        if (nv > n1)
-            JSG_HIP(e, hipMemcpy2DAsync(tile + n1, size_t(tile_pitch) * 4, e->d_img, size_t(e->img_pitch) * 4, size_t(nv - n1) * 4,
-                                        size_t(H), hipMemcpyDeviceToHost, e->stream));
-        JSG_HIP(e, hipStreamSynchronize(e->stream));
+        JSG_HIP(e, copy_cols(e, tile, tile_pitch, 0, first, n1));
+        JSG_HIP(e, copy_cols(e, tile, tile_pitch, n1, 0, nv - n1));
+        JSG_HIP(e, hipStreamSynchronize(e->rstream));
     }
-    if (new_vals) *new_vals = nv;
-    if (pos_out) *pos_out = pos;
+    e->host_fixed_valid = false;
     return JSG_OK;
 }
 

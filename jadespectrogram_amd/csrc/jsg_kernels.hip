@@ -993,6 +993,13 @@ int jsg_plan_create(jsg_plan** out, int n, const float* window, float power_scal
         delete p;
         return jsg_fail(JSG_ERR_NO_DEVICE, "jsg_plan_create: no HIP device (the engine has no CPU fallback)");
     }
+    // Force the (lazily loaded) code object onto the device now, on the thread that configures, not inside the audio
+    // thread's first jsg_process_block: querying any kernel of the module loads all of them (measured: 2.5 ms otherwise).
+    {
+        hipFuncAttributes fa;
+        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&stft_db_kernel<Cfg1024, 3>));
+        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&colormap_kernel));
+    }
     hipError_t err = hipMalloc(reinterpret_cast<void**>(&p->d_tab), t.size() * sizeof(float2));
     if (err == hipSuccess) err = hipMemcpy(p->d_tab, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice);
     if (err != hipSuccess) {
@@ -1029,6 +1036,13 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
             return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: the plan was created on another device");
     }
     if (g->channels > 65535) return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_db_launch: more than 65535 channels");
+    if (g->in_samples != 0) {   // the caller told us how long the channel rows are: refuse to read past them
+        const long long j = g->first_frame + g->n_frames - 1;
+        const long long start = ((long long)g->hop * g->feedblocks == plan->n)
+                                    ? j * g->hop : (j / g->feedblocks) * plan->n + (j % g->feedblocks) * g->hop;
+        if (g->in_samples < 0 || start + plan->n > g->in_samples || (g->channels > 1 && g->in_pitch < g->in_samples))
+            return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: the last frame would read past the end of the input rows");
+    }
     if (g->n_frames >= (1ll << 31) || g->first_frame + g->n_frames >= (1ll << 31))
         return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_db_launch: frame index does not fit 31 bits");
     StftKArgs ka{};

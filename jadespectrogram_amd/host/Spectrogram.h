@@ -3,6 +3,7 @@
 // body is a thin veneer over the C-ABI of libjsg.so, i.e. all signal processing runs in hand-written HIP kernels
 // on an MI355X.  Header-only: add this directory to the include path and link libjsg.so.
 //
+//   PluginProcessor.cpp:28        m_spectrogram.prepareParameter(m_parameterVTS)                 -> unchanged
 //   PluginProcessor.cpp:102-114   prepareToPlay: preparetoProcess / setSamplerate / setmemoryTime_s / setFFTSize /
 //                                 setfeed_percent            -> unchanged call sites
 //   PluginProcessor.cpp:148       m_spectrogram.processBlock(buffer, midi)   -> unchanged
@@ -13,10 +14,15 @@
 //   * the channel count comes from preparetoProcess()/setchannels(); the reference keeps its ctor default of 2
 //     unless the (external) base class sets it;
 //   * there is no CPU fallback: if no MI355X is usable the constructor throws std::runtime_error;
-//   * getMem synchronises with the GPU stream; processSynchronBlock only enqueues work.
+//   * the setters never throw (they run inside JUCE callbacks): a failed setter leaves the engine as it was, prints the
+//     reason to stderr and keeps it in lastError();
+//   * processSynchronBlock only enqueues work and never waits for getMem / the display (jsg.h, "threading").
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -52,15 +58,39 @@ public:
         }
         return jsg_process_block(m_engine.get(), m_ptrs.data());
     }
-    // void prepareParameter(std::unique_ptr<AudioProcessorValueTreeState>&) -- display parameters are GUI plumbing
-    // (reference Spectrogram.cpp:25-35) and stay in the plugin; nothing on the GPU depends on them.
+    // Spectrogram::prepareParameter (reference Spectrogram.cpp:25-35): remember where the four display parameters live.
+    // Nothing on the GPU depends on them; the IDs and defaults are those of reference Spectrogram.h:22-58
+    // (frequencies are log-Hz, colour limits g_minColorVal / g_maxColorVal = -50 / +50 dB, PlugInGUISettings.h:37-38).
+    void prepareParameter(std::unique_ptr<juce::AudioProcessorValueTreeState>& vts) {
+        m_SpecParameter.m_DisplayMinFreq = vts->getRawParameterValue("MinFreq");
+        m_SpecParameter.m_DisplayMinFreqOld = std::log(1.f);
+        m_SpecParameter.m_DisplayMaxFreq = vts->getRawParameterValue("MaxFreq");
+        m_SpecParameter.m_DisplayMaxFreqOld = std::log(20000.f);
+        m_SpecParameter.m_DisplayMinColor = vts->getRawParameterValue("MinColor");
+        m_SpecParameter.m_DisplayMinColorOld = -50.f;
+        m_SpecParameter.m_DisplayMaxColor = vts->getRawParameterValue("MaxColor");
+        m_SpecParameter.m_DisplayMaxColorOld = 50.f;
+    }
+    struct DisplayParameterRefs {   // the members of the reference's SpectrogramParameter (Spectrogram.h:66-75)
+        std::atomic<float>* m_DisplayMinFreq = nullptr;
+        float m_DisplayMinFreqOld = 0.f;
+        std::atomic<float>* m_DisplayMaxFreq = nullptr;
+        float m_DisplayMaxFreqOld = 0.f;
+        std::atomic<float>* m_DisplayMinColor = nullptr;
+        float m_DisplayMinColorOld = 0.f;
+        std::atomic<float>* m_DisplayMaxColor = nullptr;
+        float m_DisplayMaxColorOld = 0.f;
+    };
+    const DisplayParameterRefs& displayParameters() const { return m_SpecParameter; }
 
     // setter
     void setSamplerate(float samplerate) { check(jsg_set_samplerate(m_engine.get(), samplerate)); }
     void setchannels(size_t newchannels) { check(jsg_set_channels(m_engine.get(), int(newchannels))); }
     void setFFTSize(size_t newFFTSize) {
-        check(jsg_set_fft_size(m_engine.get(), int(newFFTSize)));
-        setDesiredBlockSizeSamples(newFFTSize);
+        // engine size and re-blocker size change together under the re-blocker's lock (the reference's m_protect,
+        // Spectrogram.cpp:162-167): the audio thread can never hand a block of the old size to the new engine
+        std::lock_guard<std::recursive_mutex> lk(syncLock());
+        if (check(jsg_set_fft_size(m_engine.get(), int(newFFTSize)))) setDesiredBlockSizeSamples(newFFTSize);
     }
     void setclosestFFTSize_ms(float fftsize_ms) { setFFTSize(getnextpowerof2(fftsize_ms)); }
     void setmemoryTime_s(float memsize_s) { check(jsg_set_memory_time_s(m_engine.get(), memsize_s)); }
@@ -77,17 +107,10 @@ public:
     int getMem(std::vector<std::vector<float>>& mem, int& pos) {
         const int W = getMemorySize(), H = getSpectrumSize();
         if (int(mem.size()) != W) return -1;   // Spectrogram.cpp:297-298
-        // getMem copies only the new columns; keep the caller's other columns by staging through a dense mirror
-        if (m_dense.size() != size_t(W) * size_t(H)) m_dense.assign(size_t(W) * size_t(H), 0.f);
-        for (int c = 0; c < W; ++c)
-            if (int(mem[size_t(c)].size()) == H) std::copy(mem[size_t(c)].begin(), mem[size_t(c)].end(), m_dense.begin() + long(c) * H);
-        const int newVals = jsg_get_mem(m_engine.get(), m_dense.data(), W, &pos);
-        if (newVals < 0) return newVals;
-        for (int c = 0; c < W; ++c) {
-            if (int(mem[size_t(c)].size()) != H) continue;
-            std::copy(m_dense.begin() + long(c) * H, m_dense.begin() + long(c + 1) * H, mem[size_t(c)].begin());
-        }
-        return newVals;
+        // the engine writes the new columns straight into the caller's rows (rows of another length are skipped)
+        m_rows.resize(size_t(W));
+        for (int c = 0; c < W; ++c) m_rows[size_t(c)] = int(mem[size_t(c)].size()) == H ? mem[size_t(c)].data() : nullptr;
+        return jsg_get_mem_rows(m_engine.get(), m_rows.data(), W, H, &pos);
     }
     float getSamplerate() { return jsg_get_samplerate(m_engine.get()); }
 
@@ -95,6 +118,7 @@ public:
     void setMixMode(ChannelMixMode m) { check(jsg_set_mix_mode(m_engine.get(), int(m))); }
     void setPowerScale(float s) { check(jsg_set_power_scale(m_engine.get(), s)); }
     jsg_engine* engine() { return m_engine.get(); }
+    const std::string& lastError() const { return m_lastError; }   // text of the last failed setter ("" if none)
 
 protected:
     void channelsPrepared(size_t channels) override {
@@ -105,12 +129,17 @@ private:
     struct Deleter {
         void operator()(jsg_engine* e) const { jsg_destroy(e); }
     };
-    void check(int rc) {
-        if (rc < 0) throw std::runtime_error(std::string("Spectrogram: ") + jsg_last_error(m_engine.get()));
+    bool check(int rc) {   // setters run inside JUCE callbacks: report, never throw
+        if (rc >= 0) return true;
+        m_lastError = jsg_last_error(m_engine.get());
+        std::fprintf(stderr, "Spectrogram (libjsg): %s\n", m_lastError.c_str());
+        return false;
     }
     std::unique_ptr<jsg_engine, Deleter> m_engine;
     std::vector<const float*> m_ptrs;
-    std::vector<float> m_dense;
+    std::vector<float*> m_rows;
+    std::string m_lastError;
+    DisplayParameterRefs m_SpecParameter;
 };
 
 // The colour half of SpectrogramComponent::timerCallback (reference Spectrogram.cpp:590-731) as one call:

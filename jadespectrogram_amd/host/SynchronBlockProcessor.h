@@ -6,9 +6,16 @@
 //   virtual processSynchronBlock(vector<vector<float>>&, MidiBuffer&)   reference Spectrogram.h:112
 // It turns host blocks of arbitrary length into fixed blocks of the desired size (the FFT size) and hands each to
 // processSynchronBlock.  The audio itself passes through untouched (the spectrogram only analyses).
+//
+// Threads: processBlock runs on the audio thread, setDesiredBlockSizeSamples / preparetoProcess on the message thread
+// (the FFT-size combo box, reference Spectrogram.cpp:760-767).  The FIFO is guarded by one lock, like the reference's
+// m_protect around processSynchronBlock and setFFTSize (Spectrogram.cpp:40,132,162,167) -- but the audio thread only
+// TRIES it: while a resize is in progress the host block is skipped instead of making the audio thread wait
+// (a resize wipes the spectrogram's history anyway, reference buildmem, Spectrogram.cpp:213-238).
 #pragma once
 #include <algorithm>
 #include <cstddef>
+#include <mutex>
 #include <vector>
 
 #include "juce_shim.h"
@@ -20,17 +27,24 @@ public:
 
     void preparetoProcess(int channels, int maxBlockSize) {
         juce::ignoreUnused(maxBlockSize);
+        std::lock_guard<std::recursive_mutex> lk(m_syncLock);
         m_syncChannels = channels > 0 ? size_t(channels) : 1;
         resetFifo();
         channelsPrepared(m_syncChannels);
     }
     void setDesiredBlockSizeSamples(size_t n) {
-        m_syncBlock = n;
+        std::lock_guard<std::recursive_mutex> lk(m_syncLock);
+        m_syncBlock = n > 0 ? n : 1;
         resetFifo();
     }
-    size_t getDesiredBlockSizeSamples() const { return m_syncBlock; }
+    size_t getDesiredBlockSizeSamples() const {
+        std::lock_guard<std::recursive_mutex> lk(m_syncLock);
+        return m_syncBlock;
+    }
 
     void processBlock(juce::AudioBuffer<float>& buffer, juce::MidiBuffer& midi) {
+        std::unique_lock<std::recursive_mutex> lk(m_syncLock, std::try_to_lock);
+        if (!lk.owns_lock()) return;   // a resize is running on the message thread: skip this host block
         const size_t ch = std::min(m_syncChannels, size_t(buffer.getNumChannels()));
         const size_t n = size_t(buffer.getNumSamples());
         size_t done = 0;
@@ -57,12 +71,15 @@ public:
 
 protected:
     virtual void channelsPrepared(size_t /*channels*/) {}
+    // for derived classes that change the block size together with their own state (Spectrogram::setFFTSize)
+    std::recursive_mutex& syncLock() { return m_syncLock; }
 
 private:
     void resetFifo() {
         m_fifo.assign(m_syncChannels, std::vector<float>(m_syncBlock, 0.f));
         m_fill = 0;
     }
+    mutable std::recursive_mutex m_syncLock;
     size_t m_syncChannels = 2;
     size_t m_syncBlock = 1024;
     size_t m_fill = 0;

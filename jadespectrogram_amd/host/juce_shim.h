@@ -6,7 +6,11 @@
 #define JSG_HAVE_JUCE 1
 #else
 #define JSG_HAVE_JUCE 0
+#include <atomic>
 #include <cstddef>
+#include <map>
+#include <memory>
+#include <string>
 #include <vector>
 namespace juce {
 class MidiBuffer {};
@@ -30,6 +34,23 @@ public:
 private:
     int m_channels = 0, m_samples = 0;
     std::vector<T> m_data;
+};
+// Holder of raw parameter values with the one accessor Spectrogram::prepareParameter uses (reference
+// Spectrogram.cpp:25-35: vts->getRawParameterValue(ID)).  The real class owns a parameter tree; this one owns a map
+// id -> value so that the call at PluginProcessor.cpp:28 compiles and can be exercised without JUCE.
+class AudioProcessorValueTreeState {
+public:
+    void addRawParameter(const std::string& id, float value) {
+        auto& p = m_values[id];
+        if (!p) p = std::make_unique<std::atomic<float>>(value);
+        else p->store(value);
+    }
+    std::atomic<float>* getRawParameterValue(const std::string& id) const {
+        auto it = m_values.find(id);
+        return it == m_values.end() ? nullptr : it->second.get();
+    }
+private:
+    std::map<std::string, std::unique_ptr<std::atomic<float>>> m_values;
 };
 }  // namespace juce
 #endif

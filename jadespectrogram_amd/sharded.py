@@ -66,8 +66,11 @@ class GpuBackend:
         return self.torch.from_numpy(np.ascontiguousarray(samples, dtype=np.float32)).to(self.device)
 
     def partial_power(self, d_samples, n_frames: int):
-        """Sum over the local channels of |X|^2 -> [n_frames][pitch] float32 on the device (no divide, no log)."""
-        out = self.torch.empty((n_frames, self.pitch), dtype=self.torch.float32, device=self.device)
+        """Sum over the local channels of |X|^2 -> [n_frames][pitch] float32 on the device (no divide, no log).
+        A rank without local channels contributes zeros (it still has to enter the all-reduce)."""
+        out = self.torch.zeros((n_frames, self.pitch), dtype=self.torch.float32, device=self.device)
+        if d_samples.shape[0] == 0:
+            return out
         self.jsg.stft_db(self.plan, d_samples, self.hop, n_frames, out, feedblocks=self.feedblocks,
                          mix_mode=self.jsg.capi.MIX_SUM, linear_out=True)
         return out
@@ -116,10 +119,19 @@ class ShardedSpectrogram:
         span = frame_span(frames, b.n, b.hop, b.feedblocks)
         if len(frames) == 0:
             return frames, None
+        if span.stop > stream_samples.shape[1]:
+            raise ValueError(f"{n_frames} frames need {span.stop} samples, the stream holds {stream_samples.shape[1]}")
         return frames, b.per_channel_db(b.to_device(stream_samples[:, span.start:span.stop]), len(frames))
 
     def absmean(self, local_samples, n_frames: int):
         """The reference's AbsMean column over ALL channels; every rank ends up with the full result."""
+        if self.world > 1:   # every rank must ask for the same columns, or the reduce would mix different frames
+            import torch
+            nf = torch.tensor([n_frames, -n_frames], dtype=torch.int64,
+                              device=getattr(self.backend, "device", None) if self.dist.get_backend(self.group) == "nccl" else "cpu")
+            self.dist.all_reduce(nf, op=self.dist.ReduceOp.MAX, group=self.group)
+            if int(nf[0]) != n_frames or int(nf[1]) != -n_frames:
+                raise ValueError("absmean: n_frames differs between ranks")
         power = self.backend.partial_power(self.backend.to_device(local_samples), n_frames)
         if self.world > 1:
             self.dist.all_reduce(power, op=self.dist.ReduceOp.SUM, group=self.group)   # the one exchange step

@@ -278,9 +278,15 @@ def _stft_args(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: 
     import torch
     assert d_in.is_cuda and d_in.dtype == torch.float32 and d_in.dim() == 2 and d_in.stride(1) == 1
     assert d_out.is_cuda and d_out.dtype == torch.float32 and d_out.stride(-1) == 1
+    H = plan.n // 2 + 1
+    if d_out.shape[-1] < H:
+        raise JsgError(capi.JSG_ERR_INVALID, f"output rows hold {d_out.shape[-1]} floats, a column needs {H}")
+    if mix_mode == capi.MIX_PER_CHANNEL and (d_out.dim() != 3 or d_out.shape[0] != d_in.shape[0]):
+        raise JsgError(capi.JSG_ERR_INVALID, "per-channel mode needs an output of [channels][W][pitch]")
     a = capi.StftArgs()
     a.in_ = d_in.data_ptr()
-    a.in_pitch = d_in.stride(0)
+    a.in_pitch = d_in.stride(0) if d_in.shape[0] > 1 else d_in.shape[1]
+    a.in_samples = d_in.shape[1]      # the launcher refuses frames that would read past the rows
     a.channels = d_in.shape[0]
     a.hop = hop
     a.feedblocks = feedblocks if feedblocks is not None else max(1, plan.n // hop)

@@ -1,0 +1,116 @@
+// Audio-thread latency of jsg_process_block while a GUI thread reads as hard as it can (C-ABI, GPU box).
+//   C5 geometry: stereo 96 kHz, 4096-point FFT, hop 512 (87.5 % overlap), 10 s memory -> ring 1875 x 2049, 15 MB image.
+// The producer pushes `blocks` fft-size blocks at a real-time-like pace and records how long every call takes; a consumer
+// thread alternates jsg_get_mem (up to 15 MB device-to-host) and jsg_display_update (colour kernel + 15 MB image copy)
+// without pause.  Afterwards the ring must be bit-identical to a second engine that was fed the same samples in one
+// batch, undisturbed.  Prints one JSON line; the pytest wrapper asserts the bounds.
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../include/jsg.h"
+
+#define CK(call)                                                                     \
+    do {                                                                             \
+        int rc_ = (call);                                                            \
+        if (rc_ < 0) {                                                               \
+            std::fprintf(stderr, "%s -> %d: %s\n", #call, rc_, jsg_last_error(nullptr)); \
+            return 2;                                                                \
+        }                                                                            \
+    } while (0)
+
+static int configure(jsg_engine* e) {
+    CK(jsg_set_samplerate(e, 96000.f));
+    CK(jsg_set_memory_time_s(e, 10.f));
+    CK(jsg_set_fft_size(e, 4096));
+    CK(jsg_set_feed_percent_ext(e, 12.5f));
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    const int blocks = argc > 1 ? std::atoi(argv[1]) : 300;
+    const int pace_us = argc > 2 ? std::atoi(argv[2]) : 500;   // pause between blocks (a 4096-sample block at 96 kHz lasts 42.7 ms)
+    const int C = 2, N = 4096;
+    jsg_engine *live = nullptr, *batch = nullptr;
+    CK(jsg_create(&live, C));
+    CK(jsg_create(&batch, C));
+    if (configure(live) || configure(batch)) return 2;
+    const int W = jsg_get_memory_size(live), H = jsg_get_spectrum_size(live);
+    std::vector<float> x(size_t(C) * size_t(blocks) * N);
+    unsigned s = 777u;
+    for (size_t i = 0; i < x.size(); ++i) {
+        s = s * 1664525u + 1013904223u;
+        x[i] = 0.4f * std::sin(0.01f * float(i % 9973)) + 0.2f * (float(int(s >> 9)) / 4194304.0f - 1.0f);
+    }
+    const size_t chan_pitch = size_t(blocks) * N;   // planar: channel c at x[c*chan_pitch ...]
+
+    std::atomic<bool> stop{false};
+    std::atomic<long> reads{0}, read_columns{0};
+    std::atomic<int> reader_rc{0};
+    std::thread consumer([&] {
+        std::vector<float> mem(size_t(W) * H);
+        std::vector<uint32_t> img(size_t(W) * H);
+        int k = 0;
+        while (!stop.load()) {
+            int pos = 0, nv = 0;
+            int rc = (k++ & 1) ? jsg_get_mem(live, mem.data(), W, &pos) : jsg_display_update(live, -50.f, 50.f, img.data(), W, &nv, &pos);
+            if (rc < 0) { reader_rc.store(rc); break; }
+            if (k & 1) read_columns += rc < 1000000 ? rc : 0;
+            ++reads;
+            if ((k % 7) == 0) jsg_display_invalidate(live);   // force full recolours as well
+        }
+    });
+
+    std::vector<double> lat;
+    lat.reserve(size_t(blocks));
+    for (int b = 0; b < blocks; ++b) {
+        const float* ptrs[2] = {x.data() + size_t(b) * N, x.data() + chan_pitch + size_t(b) * N};
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = jsg_process_block(live, ptrs);
+        const auto t1 = std::chrono::steady_clock::now();
+        if (rc < 0) { std::fprintf(stderr, "process_block: %s\n", jsg_last_error(live)); stop = true; consumer.join(); return 2; }
+        lat.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
+        if (pace_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(pace_us));
+    }
+    stop = true;
+    consumer.join();
+    if (reader_rc.load() < 0) { std::fprintf(stderr, "reader failed: %s\n", jsg_last_error(live)); return 2; }
+    CK(jsg_sync(live));
+
+    // reference run: the same samples, one batch, nobody reading
+    CK(jsg_process_blocks(batch, x.data(), int64_t(chan_pitch), blocks));
+    // both rings, column for column, without touching the new-column counters
+    std::vector<float> a(size_t(W) * H), r(size_t(W) * H);
+    int pa = -1, pr = -1;
+    CK(jsg_peek_mem(live, a.data(), W, &pa));
+    CK(jsg_peek_mem(batch, r.data(), W, &pr));
+    size_t diff_floats = 0;
+    for (size_t i = 0; i < a.size(); ++i) diff_floats += std::memcmp(&a[i], &r[i], 4) != 0;
+    // and the images of a full recolour
+    std::vector<uint32_t> ia(size_t(W) * H), ib(size_t(W) * H);
+    int nva = 0, nvb = 0, qa = 0, qb = 0;
+    CK(jsg_display_invalidate(live));
+    CK(jsg_display_invalidate(batch));
+    CK(jsg_display_update(live, -50.f, 50.f, ia.data(), W, &nva, &qa));
+    CK(jsg_display_update(batch, -50.f, 50.f, ib.data(), W, &nvb, &qb));
+    size_t diff_px = 0;
+    for (size_t i = 0; i < ia.size(); ++i) diff_px += ia[i] != ib[i];
+    const double first_us = lat.empty() ? 0.0 : lat[0];
+    size_t worst_at = 0;
+    for (size_t i = 1; i < lat.size(); ++i) if (lat[i] > lat[worst_at]) worst_at = i;
+    const double max_after_first = lat.size() > 1 ? *std::max_element(lat.begin() + 1, lat.end()) : 0.0;
+    std::sort(lat.begin(), lat.end());
+    auto pct = [&](double q) { return lat[size_t(q * double(lat.size() - 1))]; };
+    std::printf("{\"blocks\": %d, \"W\": %d, \"H\": %d, \"reads\": %ld, \"p50_us\": %.1f, \"p99_us\": %.1f, \"max_us\": %.1f, \"first_call_us\": %.1f, \"max_after_first_us\": %.1f, \"worst_call\": %zu, "
+                "\"pos_live\": %d, \"pos_batch\": %d, \"differing_floats\": %zu, \"differing_pixels\": %zu}\n",
+                blocks, W, H, reads.load(), pct(0.5), pct(0.99), lat.back(), first_us, max_after_first, worst_at, pa, pr, diff_floats, diff_px);
+    jsg_destroy(live);
+    jsg_destroy(batch);
+    return 0;
+}

@@ -1,0 +1,45 @@
+// CPU-only, built with -fsanitize=thread (and once more with address,undefined): the audio thread runs processBlock while
+// the message thread changes the block size (the FFT-size combo box, reference Spectrogram.cpp:760-767).  The reference
+// guards both with m_protect; the stand-in must be free of data races and must never hand out a block of a stale size.
+#include <atomic>
+#include <cstdio>
+#include <thread>
+#include <vector>
+
+#include "../../jadespectrogram_amd/host/SynchronBlockProcessor.h"
+
+struct Probe : SynchronBlockProcessor {
+    std::atomic<long> calls{0}, bad{0};
+    int processSynchronBlock(std::vector<std::vector<float>>& data, juce::MidiBuffer&) override {
+        ++calls;
+        // called under the re-blocker's lock: the size it was filled for is the size that is current
+        if (data.size() != 2 || data[0].size() != getDesiredBlockSizeSamples() || data[1].size() != data[0].size()) ++bad;
+        return 0;
+    }
+};
+
+int main() {
+    Probe p;
+    p.preparetoProcess(2, 512);
+    p.setDesiredBlockSizeSamples(1024);
+    std::atomic<bool> stop{false};
+    std::thread gui([&] {
+        const size_t sizes[] = {512, 1024, 2048, 4096, 8192};
+        for (int i = 0; i < 400; ++i) {
+            p.setDesiredBlockSizeSamples(sizes[i % 5]);
+            if (i % 50 == 0) p.preparetoProcess(2, 480);
+            std::this_thread::yield();
+        }
+        stop = true;
+    });
+    juce::MidiBuffer midi;
+    juce::AudioBuffer<float> buf(2, 480);
+    long host_blocks = 0;
+    while (!stop.load()) {
+        p.processBlock(buf, midi);
+        ++host_blocks;
+    }
+    gui.join();
+    std::printf("host blocks %ld, synchron blocks %ld, bad %ld\n", host_blocks, p.calls.load(), p.bad.load());
+    return p.bad.load() == 0 ? 0 : 1;
+}

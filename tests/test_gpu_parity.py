@@ -252,6 +252,19 @@ def test_empty_inputs_and_bad_geometry(jsg, oracle, torch_cuda):
         jsg.stft_db(plan, d_in, 512, 5, d_out)
     with pytest.raises(jsg.JsgError):                                      # column pitch smaller than n/2+1
         jsg.stft_db(plan, d_in, 512, 2, torch.zeros((4, 512), device="cuda"))
+    # a frame count that reaches past the end of the input rows is refused, not read (4n samples hold
+    # 7 frames at hop n/2; the 8th would read n/2 floats past the allocation)
+    big = torch.zeros((16, 544), device="cuda")
+    jsg.stft_db(plan, d_in, 512, 7, big)
+    with pytest.raises(jsg.JsgError, match="past the end"):
+        jsg.stft_db(plan, d_in, 512, 8, big)
+    with pytest.raises(jsg.JsgError, match="past the end"):
+        jsg.stft_db(plan, d_in, 512, 4, big, first_frame=4)
+    with pytest.raises(jsg.JsgError, match="past the end"):               # irregular (perc10-style) framing: 10 frames per block
+        jsg.stft_db(plan, d_in, 102, 16, torch.zeros((64, 544), device="cuda"), feedblocks=10, first_frame=30)
+    with pytest.raises(jsg.JsgError):                                      # per-channel output must have one plane per channel
+        jsg.stft_db(plan, torch.zeros((2, 4 * n), device="cuda"), 512, 2, big, mix_mode=jsg.capi.MIX_PER_CHANNEL)
+    torch.cuda.synchronize()
     s = jsg.Spectrogram(1)
     s.setFFTSize(n)
     assert s.processBlocks(np.zeros((1, 0), np.float32)) == 0             # empty batch

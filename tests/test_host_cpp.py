@@ -64,3 +64,87 @@ def test_reblocker_stand_in_cpu():
     src = os.path.join(ROOT, "tests", "cpp", "reblocker_test.cpp")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", src, "-o", exe])
     assert subprocess.call([exe]) == 0
+
+
+def _cxx(args, exe):
+    subprocess.check_call(["g++", "-std=c++17", "-g", "-I", os.path.join(ROOT, "include")] + args + ["-o", exe])
+    return exe
+
+
+def test_host_math_entry_points_under_asan_ubsan(jsg):
+    """the CPU build of the host-math half of the C-ABI runs clean under address + undefined-behaviour
+    sanitizers over its whole parameter range, and computes exactly what the shipped library computes."""
+    d = tempfile.gettempdir()
+    drv = os.path.join(ROOT, "tests", "cpp", "host_math_sanitize_test.cpp")
+    hm = os.path.join(ROOT, "jadespectrogram_amd", "csrc", "jsg_host_math.cpp")
+    san = _cxx(["-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-ffp-contract=off", hm, drv],
+               os.path.join(d, "jsg_hm_san"))
+    libdir = os.path.dirname(jsg.capi.LIB_PATH)
+    shipped = _cxx(["-O1", drv, "-L", libdir, "-ljsg", f"-Wl,-rpath,{libdir}"], os.path.join(d, "jsg_hm_lib"))
+    h_san = subprocess.check_output([san]).decode().strip()
+    h_lib = subprocess.check_output([shipped]).decode().strip()
+    assert len(h_san) == 16 and h_san == h_lib
+
+
+@pytest.mark.parametrize("flags", [["-fsanitize=thread"], ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"]])
+def test_reblocker_resize_race_under_sanitizers(flags):
+    """ADVICE (round 1): setFFTSize -> setDesiredBlockSizeSamples from the message thread while the audio thread is inside
+    processBlock.  ThreadSanitizer / ASan+UBSan builds of the stand-in must report nothing and never see a stale block size."""
+    d = tempfile.gettempdir()
+    exe = _cxx(["-O1"] + flags + [os.path.join(ROOT, "tests", "cpp", "reblocker_race_test.cpp"), "-lpthread"],
+               os.path.join(d, "jsg_rb_race_" + flags[0].split("=")[1].split(",")[0]))
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bad 0" in r.stdout and "WARNING" not in r.stderr
+    exe2 = _cxx(["-O1"] + flags + [os.path.join(ROOT, "tests", "cpp", "reblocker_test.cpp"), "-lpthread"],
+                os.path.join(d, "jsg_rb_" + flags[0].split("=")[1].split(",")[0]))
+    assert subprocess.call([exe2]) == 0
+
+
+def _build_against_lib(jsg, src, name):
+    libdir = os.path.dirname(jsg.capi.LIB_PATH)
+    exe = os.path.join(tempfile.gettempdir(), name)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", src), "-o", exe, "-L", libdir, "-ljsg", f"-Wl,-rpath,{libdir}",
+                           "-lpthread"])
+    return exe
+
+
+def test_plugin_callshape_driver_compiles(jsg):
+    """PluginProcessor.cpp:20-28 (prepareParameter), :102-114, :145-150 and Spectrogram.cpp:592-608 against the drop-in headers."""
+    assert os.path.exists(_build_against_lib(jsg, "plugin_callshape_test.cpp", "jsg_plugin_callshape"))
+    assert os.path.exists(_build_against_lib(jsg, "producer_latency_test.cpp", "jsg_producer_latency"))
+
+
+@pytest.mark.gpu
+def test_plugin_callshape_runs(jsg):
+    exe = _build_against_lib(jsg, "plugin_callshape_test.cpp", "jsg_plugin_callshape")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    # prepareToPlay: 48 kHz, 10 s, 2048-point FFT, 50 % feed -> hop 1024, 469 columns of 1025 bins (SURVEY section 4)
+    # 64 host blocks of 480 samples = 15 fft blocks = 30 columns; ticks after 3 / 7 / 11 / 15 blocks -> 8 new columns each
+    assert info["new_between_ticks"] == 24
+    # after the FFT-size combo: 1024-point, 16 x 480 samples = 7 blocks = 14 columns on top of the start-up sentinel
+    assert (info["W"], info["H"]) == (938, 513)
+    assert info["new_after_resize"] == 1215752192 + 14
+    assert info["peak_bin"] == 21 and abs(info["peak_db"] - 51.7976) < 0.05      # SURVEY KAT: full-scale 1 kHz sine
+    assert info["fft_after_bad_setter"] == 1024 and info["last_error_set"] == 1   # a refused size throws nothing, changes nothing
+
+
+@pytest.mark.gpu
+def test_producer_never_waits_for_the_consumer(jsg):
+    """a GUI thread hammering getMem / display_update on a C5-sized ring (1875 x 2049, 15 MB per read)
+    must not hold up jsg_process_block, and the ring must end up bit-identical to an undisturbed batch run."""
+    exe = _build_against_lib(jsg, "producer_latency_test.cpp", "jsg_producer_latency")
+    r = subprocess.run([exe, "400", "300"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    print("producer latency under reader load:", info)
+    assert (info["W"], info["H"]) == (1875, 2049)
+    assert info["reads"] >= 20                      # the consumer really was busy
+    assert info["differing_floats"] == 0 and info["differing_pixels"] == 0 and info["pos_live"] == info["pos_batch"]
+    # one consumer read moves 15 MB over PCIe (hundreds of microseconds); the producer's call stays far below that
+    assert info["p99_us"] < 150.0, info
+    assert info["p50_us"] < 60.0, info
+    assert info["max_after_first_us"] < 1500.0, info   # no call ever waits for a reader's PCIe copy (those take milliseconds)

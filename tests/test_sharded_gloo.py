@@ -136,3 +136,62 @@ def test_world_size_2_absmean_and_per_channel(oracle):
     # AbsMean across shards: equal to the reference's sequential float sum up to float32 re-association
     ref_mix = oracle.to_db(oracle.mix_channels(single._power(x, F), oracle.MIX_ABSMEAN))
     assert np.abs(mixed - ref_mix).max() < 1e-4
+
+
+def _worker_edge(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch.distributed as dist
+    from oracle import jsg_oracle as oracle
+    from jadespectrogram_amd.sharded import ShardedSpectrogram
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, hop, F = 1024, 512, 4
+    win = oracle.window(oracle.WIN_HANN, n)
+    x = oracle.synth_audio(1, F * hop + n, seed=5)               # ONE channel on two ranks: rank 1 has no channel
+    sh = ShardedSpectrogram(1, OracleBackend(oracle, n, hop, win))
+    mine = sh.local_channels()
+    mixed = sh.absmean(x[mine.start:mine.stop], F).numpy()       # must not hang in the all-reduce
+    # frame counts that differ between the ranks are refused on every rank (before any data is reduced)
+    try:
+        sh.absmean(x[mine.start:mine.stop], F - rank)
+        refused = False
+    except ValueError:
+        refused = True
+    # a stream that is too short for the requested frames is refused instead of being silently truncated
+    try:
+        sh.time_sharded(x[:, :(F - 1) * hop + n - 1], F)       # one sample short of what the last frame reads
+        short_refused = False
+    except ValueError:
+        short_refused = True
+    got = [None] * world
+    dist.all_gather_object(got, (len(mine), refused, short_refused))
+    if rank == 0:
+        q.put((mixed, got))
+    dist.destroy_process_group()
+
+
+def test_world_size_2_empty_shard_and_mismatched_requests(oracle):
+    """a rank without channels still enters the all-reduce with zeros; unequal n_frames and short streams raise."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_edge, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    mixed, got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [g[0] for g in got] == [1, 0]
+    assert all(g[1] for g in got)
+    # only the last rank's run of frames reaches the end of the stream, so only that rank notices the missing sample
+    assert got[1][2]
+    n, hop, F = 1024, 512, 4
+    win = oracle.window(oracle.WIN_HANN, n)
+    x = oracle.synth_audio(1, F * hop + n, seed=5)
+    single = OracleBackend(oracle, n, hop, win)
+    ref = oracle.to_db(oracle.mix_channels(single._power(x, F), oracle.MIX_ABSMEAN))
+    assert (mixed.view(np.uint32) == ref.view(np.uint32)).all()
