@@ -173,6 +173,21 @@ typedef struct jsg_colormap_args {
 } jsg_colormap_args;
 int jsg_colormap_launch(const jsg_colormap_args* args, void* stream);
 
+/* Fused display path: STFT -> palette index -> ARGB without the dB column ever going to memory (reference
+ * Spectrogram.cpp:632-648: the colour loop consumes the column the engine has just produced).  Two kernels on `stream`:
+ * the STFT kernel with an epilogue that writes 1 byte per bin (CColorPalette::getRGBColor's index, CColorpalette.h:34-45)
+ * into `index_scratch`, and the colour kernel reading those bytes.  The image is bit-identical to jsg_stft_db_launch
+ * followed by jsg_colormap_launch.  stft.out_db may be NULL (it is not written); colour.db is ignored; colour must
+ * cover exactly the columns of the launch (n_cols == n_frames, col_first == ring_pos, ring_width equal, height n/2+1);
+ * n_colors <= 256; mixes: AbsMean / Sum / Left / Right. */
+typedef struct jsg_stft_image_args {
+    jsg_stft_args stft;
+    jsg_colormap_args colour;
+    uint8_t* index_scratch;        /* device: ring_width columns of index_scratch_pitch bytes each */
+    int64_t index_scratch_pitch;   /* >= n/2+1; a multiple of 64 keeps the columns line-aligned */
+} jsg_stft_image_args;
+int jsg_stft_image_launch(const jsg_plan* plan, const jsg_stft_image_args* args, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * 3. Engine: the state of class Spectrogram (Spectrogram.h:81-169) living on the GPU.
  * ------------------------------------------------------------------------------------------------ */

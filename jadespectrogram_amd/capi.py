@@ -49,6 +49,10 @@ class ColormapArgs(C.Structure):
                 ("index_out", C.c_void_p), ("index_pitch", C.c_int64)]
 
 
+class StftImageArgs(C.Structure):
+    _fields_ = [("stft", StftArgs), ("colour", ColormapArgs), ("index_scratch", C.c_void_p), ("index_scratch_pitch", C.c_int64)]
+
+
 # every symbol include/jsg.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SIGNATURES = {
@@ -66,6 +70,7 @@ SIGNATURES = {
     "jsg_stft_db_launch": (C.c_int, [_P, C.POINTER(StftArgs), _P]),
     "jsg_stft_db_launch_many": (C.c_int, [_P, C.POINTER(StftArgs), C.c_int, C.POINTER(_P), C.c_int]),
     "jsg_colormap_launch": (C.c_int, [C.POINTER(ColormapArgs), _P]),
+    "jsg_stft_image_launch": (C.c_int, [_P, C.POINTER(StftImageArgs), _P]),
     "jsg_db_from_power_launch": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
     "jsg_create": (C.c_int, [C.POINTER(_P), C.c_int]),
     "jsg_create_on_device": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int]),

@@ -265,6 +265,11 @@ struct StftKArgs {
     unsigned long long* stamps;   // development (ABL == 3): 4 s_memtime stamps per wave
     int xcd_remap;                // 1: XCD-aware block remap (default); 0: identity (development A/B)
     int chunked;                  // 0: grid-stride traversal (default); 1: one contiguous chunk per workgroup
+    // OUTK == 1 (fused display path): the column leaves as 8-bit palette indices instead of dB floats
+    unsigned char* idx;
+    long long idx_pitch;          // bytes between index columns
+    float vmin, vmax, top, mult;  // CColorPalette::setValueRange / getRGBColor (CColorpalette.cpp:39-54, CColorpalette.h:34-45)
+    int n_colors;
 };
 
 // dB = 10*log10(p + 1e-11f) -- reference Spectrogram.cpp:107 with g_minValForLogSpectrogram (:36).
@@ -279,6 +284,14 @@ __device__ __forceinline__ cf to_db2(cf p) {
     p = p + cf{1e-11f, 1e-11f};
     cf r = {__builtin_amdgcn_logf(p.x), __builtin_amdgcn_logf(p.y)};
     return r * cf{3.0102999566398120f, 3.0102999566398120f};
+}
+
+// CColorPalette::getRGBColor's index (reference CColorpalette.h:34-45), float32 arithmetic, truncation.
+__device__ __forceinline__ int color_index(float v, float vmin, float vmax, float top, float mult, int n_colors) {
+    if (v >= vmax) v = top;          // value = m_Max*0.9999f
+    if (v < vmin) v = vmin;
+    int idx = (int)((v - vmin) * mult);
+    return idx < n_colors ? idx : n_colors - 1;
 }
 
 template <int MIXOP>
@@ -305,7 +318,9 @@ __device__ __forceinline__ float mix_combine(float acc, float pw) {
 #else
 #define JSG_NO_LDS_MERGE
 #endif
-template <class C, int MIXOP>
+// OUTK: 0 = the column is stored as floats (dB, or linear power), 1 = as 8-bit palette indices (fused display path:
+// the dB value never goes to memory; reference Spectrogram.cpp:632-648 consumes the column it has just produced).
+template <class C, int MIXOP, int OUTK = 0>
 __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_kernel(
     // Everything the table and frame loads depend on sits in the first 16 dwords of the kernel arguments: with
     // -amdgpu-kernarg-preload-count=16 those arrive in SGPRs with the wave, so the loads are issued without waiting for a
@@ -672,6 +687,16 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
 #endif
                 accNy = to_db(accNy);
             }
+            if constexpr (OUTK == 1) {
+                // palette index of every bin; 64 consecutive bytes of the index column per store instruction
+                unsigned char* ic = a.idx + (long long)col * a.idx_pitch;
+#pragma unroll
+                for (int rho = 0; rho < P / 2; ++rho) {
+                    ic[ll + L * rho] = (unsigned char)color_index(acc[rho], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
+                    ic[M - (ll + L * rho)] = (unsigned char)color_index(acc[P / 2 + rho], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
+                }
+                if (L <= 64 || ll == 0) ic[M / 2] = (unsigned char)color_index(accNy, a.vmin, a.vmax, a.top, a.mult, a.n_colors);
+            } else
             if constexpr (C::ABLX == 13 || C::ABLX == 14) {
                 // ablation: the same bytes as two 16-byte stores per lane (results meaningless)
                 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -745,15 +770,10 @@ struct CmapKArgs {
     long long argb_pitch;
     unsigned char* index;
     long long index_pitch;
+    const unsigned char* idx_in;   // fused display path: palette indices per column (1 byte per bin) instead of dB
+    long long idx_in_pitch;
 };
 
-// CColorPalette::getRGBColor's index (reference CColorpalette.h:34-45), float32 arithmetic, truncation.
-__device__ __forceinline__ int color_index(float v, float vmin, float vmax, float top, float mult, int n_colors) {
-    if (v >= vmax) v = top;          // value = m_Max*0.9999f
-    if (v < vmin) v = vmin;
-    int idx = (int)((v - vmin) * mult);
-    return idx < n_colors ? idx : n_colors - 1;
-}
 
 constexpr int CM_TILE = 64;   // 64 columns x 64 bins per workgroup
 
@@ -768,19 +788,34 @@ __global__ __launch_bounds__(256) void colormap_kernel(const CmapKArgs a) {
     // read phase: each wave takes 16 columns; lane = bin (256 B coalesced per column).  All 16 loads are issued
     // before the first use (one HBM round trip per tile instead of sixteen).
     const int bin = bin0 + lane;
-    float v[CM_TILE / 4];
+    if (a.idx_in) {   // the STFT kernel has already quantised the column (wave-uniform branch)
+        unsigned char b[CM_TILE / 4];
 #pragma unroll
-    for (int q = 0; q < CM_TILE / 4; ++q) {
-        const int i = col0 + wave + 4 * q;
-        int col = a.col_first + i;               // col_first < ring_w and i < n_cols <= ring_w
-        if (col >= a.ring_w) col -= a.ring_w;
-        v[q] = (i < a.n_cols && bin < a.height) ? a.db[(long long)col * a.db_pitch + bin] : 0.f;
+        for (int q = 0; q < CM_TILE / 4; ++q) {
+            const int i = col0 + wave + 4 * q;
+            int col = a.col_first + i;
+            if (col >= a.ring_w) col -= a.ring_w;
+            b[q] = (i < a.n_cols && bin < a.height) ? a.idx_in[(long long)col * a.idx_in_pitch + bin] : (unsigned char)0;
+        }
+        if (lut_in_lds)
+            for (int i = tid; i < a.n_colors; i += 256) s_lut[i] = a.lut[i];
+#pragma unroll
+        for (int q = 0; q < CM_TILE / 4; ++q) s_idx[lane][wave + 4 * q] = b[q];
+    } else {
+        float v[CM_TILE / 4];
+#pragma unroll
+        for (int q = 0; q < CM_TILE / 4; ++q) {
+            const int i = col0 + wave + 4 * q;
+            int col = a.col_first + i;               // col_first < ring_w and i < n_cols <= ring_w
+            if (col >= a.ring_w) col -= a.ring_w;
+            v[q] = (i < a.n_cols && bin < a.height) ? a.db[(long long)col * a.db_pitch + bin] : 0.f;
+        }
+        if (lut_in_lds)   // table load behind the tile loads: one latency, not two
+            for (int i = tid; i < a.n_colors; i += 256) s_lut[i] = a.lut[i];
+#pragma unroll
+        for (int q = 0; q < CM_TILE / 4; ++q)
+            s_idx[lane][wave + 4 * q] = (unsigned short)color_index(v[q], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
     }
-    if (lut_in_lds)   // table load behind the tile loads: one latency, not two
-        for (int i = tid; i < a.n_colors; i += 256) s_lut[i] = a.lut[i];
-#pragma unroll
-    for (int q = 0; q < CM_TILE / 4; ++q)
-        s_idx[lane][wave + 4 * q] = (unsigned short)color_index(v[q], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
     __syncthreads();
     // write phase: each wave takes 16 image rows; lane = column (256 B coalesced per row when x does not wrap)
     const int i = col0 + lane;
@@ -847,26 +882,31 @@ static void fill_tables(std::vector<float2>& t, const float* window, double amp)
     }
 }
 
-template <class C, int MIXOP>
+template <class C, int MIXOP, int OUTK = 0>
 static hipError_t launch_stft_mix(const StftKArgs& ka, dim3 grid, hipStream_t s) {
     static std::atomic<bool> attr_done[64];   // set once per device; setting it twice from two threads is harmless
     int dev = 0;
     hipError_t err = hipGetDevice(&dev);
     if (err != hipSuccess) return err;
     if (C::LDS_BYTES > 48 * 1024 && dev >= 0 && dev < 64 && !attr_done[dev].load(std::memory_order_acquire)) {
-        err = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_db_kernel<C, MIXOP>),
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_db_kernel<C, MIXOP, OUTK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (err != hipSuccess) return err;
         attr_done[dev].store(true, std::memory_order_release);
     }
     const int flags = (ka.regular ? 1 : 0) | (ka.per_channel ? 2 : 0) | (ka.xcd_remap ? 4 : 0) | (ka.chunked ? 8 : 0);
-    hipLaunchKernelGGL((stft_db_kernel<C, MIXOP>), grid, dim3(C::WPB * 64), C::LDS_BYTES, s, ka.in, ka.in_pitch, ka.tab, ka.n_frames,
+    hipLaunchKernelGGL((stft_db_kernel<C, MIXOP, OUTK>), grid, dim3(C::WPB * 64), C::LDS_BYTES, s, ka.in, ka.in_pitch, ka.tab, ka.n_frames,
                        ka.first_frame, ka.hop, flags, unsigned(ka.c_begin) | unsigned(ka.c_end) << 16, ka.iters, grid.x, ka.feedblocks, ka);
     return hipGetLastError();
 }
 
 template <class C>
 static hipError_t launch_stft(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s) {
+    if (ka.idx) {   // fused display path: the mixed (AbsMean / Sum) and the one-channel instantiations only
+        if (mixop == 3) return launch_stft_mix<C, 3, 1>(ka, grid, s);
+        if (mixop == 0) return launch_stft_mix<C, 0, 1>(ka, grid, s);
+        return hipErrorInvalidValue;
+    }
     switch (mixop) {
         case 1: return launch_stft_mix<C, 1>(ka, grid, s);
         case 2: return launch_stft_mix<C, 2>(ka, grid, s);
@@ -1020,14 +1060,27 @@ int jsg_plan_destroy(jsg_plan* plan) {
 
 int jsg_plan_fft_size(const jsg_plan* plan) { return plan ? plan->n : JSG_ERR_INVALID; }
 
-int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* stream) {
+}   // extern "C"
+
+namespace {
+struct IndexOut {   // fused display path: where and how the palette indices of the columns are written
+    unsigned char* idx;
+    long long pitch;
+    float vmin, vmax, mult;
+    int n_colors;
+};
+}  // namespace
+
+static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const IndexOut* io, void* stream) {
     if (!plan || !g) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: null argument");
     if (g->n_frames == 0) return JSG_OK;
     const int H = plan->n / 2 + 1;
-    if (!g->in || !g->out_db || g->channels <= 0 || g->hop <= 0 || g->feedblocks <= 0 || g->n_frames < 0 ||
+    if (!g->in || (!io && !g->out_db) || g->channels <= 0 || g->hop <= 0 || g->feedblocks <= 0 || g->n_frames < 0 ||
         g->first_frame < 0 || g->ring_width <= 0 || g->ring_pos < 0 || g->ring_pos >= g->ring_width ||
-        g->out_pitch < H)
+        (!io && g->out_pitch < H))
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: bad geometry");
+    if (io && (!io->idx || io->pitch < H || io->n_colors <= 0 || io->n_colors > 256 || g->linear_out))
+        return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch: bad index scratch (needs n_colors <= 256, pitch >= n/2+1, dB mode)");
     if (g->n_frames > g->ring_width)
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: more frames than ring columns in one launch (columns would race)");
     {
@@ -1060,6 +1113,15 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
     ka.ring_pos = g->ring_pos;
     ka.tab = plan->d_tab;
     ka.stamps = g_dev_stamps;
+    if (io) {
+        ka.idx = io->idx;
+        ka.idx_pitch = io->pitch;
+        ka.vmin = io->vmin;
+        ka.vmax = io->vmax;
+        ka.top = io->vmax * 0.9999f;
+        ka.mult = io->mult;
+        ka.n_colors = io->n_colors;
+    }
     static const int xcd_remap = getenv("JSG_NO_XCD_REMAP") ? 0 : 1;
     ka.xcd_remap = xcd_remap;
     static const int chunked = [] { const char* e = getenv("JSG_TRAVERSAL"); return (e && e[0] == 'c') ? 1 : 0; }();
@@ -1096,6 +1158,8 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
     ka.linear = g->linear_out ? 1 : 0;
     // one channel per column and nothing to scale: the specialised instantiation (see stft_db_kernel)
     if (mixop == 0 && (ka.per_channel || ka.c_end - ka.c_begin == 1) && ka.scale == 1.0f && !ka.exact_div) mixop = 3;
+    if (io && (ka.per_channel || (mixop != 0 && mixop != 3)))
+        return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_image_launch: AbsMean / Sum / Left / Right mixes only");
     int tpb = 0;
     switch (plan->n) {
         case 512: tpb = Cfg512::TPB; break;
@@ -1169,6 +1233,30 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* strea
     return JSG_OK;
 }
 
+extern "C" {
+
+int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* stream) { return stft_launch_impl(plan, g, nullptr, stream); }
+
+static int colormap_launch_impl(const jsg_colormap_args* g, const unsigned char* idx_in, long long idx_in_pitch, void* stream);
+
+// Fused display path (reference Spectrogram.cpp:632-648: the colour loop consumes the column it has just been given):
+// the STFT kernel's epilogue maps every bin to its palette index (CColorPalette::getRGBColor) and writes 1 byte per bin
+// into `index_scratch` -- the dB column never goes to memory -- and the colour kernel turns those columns into ARGB
+// image rows through its LDS transpose tiles.  Per column of C5: 4096 B in + 2049 B + 2049 B + 8196 B instead of
+// 4096 + 8196 + 8196 + 8196 B.  The image is bit-identical to jsg_stft_db_launch + jsg_colormap_launch.
+int jsg_stft_image_launch(const jsg_plan* plan, const jsg_stft_image_args* g, void* stream) {
+    if (!plan || !g) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch: null argument");
+    if (g->stft.n_frames == 0) return JSG_OK;
+    const jsg_colormap_args& c = g->colour;
+    if (c.n_cols != g->stft.n_frames || c.ring_width != g->stft.ring_width || c.height != plan->n / 2 + 1 ||
+        (c.col_first % c.ring_width) != g->stft.ring_pos)
+        return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch: the colour loop must cover exactly the columns of the launch");
+    IndexOut io{g->index_scratch, (long long)g->index_scratch_pitch, c.vmin, c.vmax, c.access_mult, c.n_colors};
+    int rc = stft_launch_impl(plan, &g->stft, &io, stream);
+    if (rc != JSG_OK) return rc;
+    return colormap_launch_impl(&c, g->index_scratch, (long long)g->index_scratch_pitch, stream);
+}
+
 int jsg_stft_db_launch_many(const jsg_plan* plan, const jsg_stft_args* args, int count, void* const* streams, int n_streams) {
     if (!plan || (!args && count > 0) || count < 0 || n_streams < 0 || (n_streams > 0 && !streams))
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch_many: bad argument");
@@ -1191,10 +1279,12 @@ int jsg_db_from_power_launch(const float* power, float* out, int64_t count, floa
     return JSG_OK;
 }
 
-int jsg_colormap_launch(const jsg_colormap_args* g, void* stream) {
+int jsg_colormap_launch(const jsg_colormap_args* g, void* stream) { return colormap_launch_impl(g, nullptr, 0, stream); }
+
+static int colormap_launch_impl(const jsg_colormap_args* g, const unsigned char* idx_in, long long idx_in_pitch, void* stream) {
     if (!g) return jsg_fail(JSG_ERR_INVALID, "jsg_colormap_launch: null argument");
     if (g->n_cols == 0) return JSG_OK;
-    if (!g->db || !g->lut || g->height <= 0 || g->ring_width <= 0 || g->n_cols < 0 || g->x_wrap <= 0 ||
+    if ((!g->db && !idx_in) || !g->lut || g->height <= 0 || g->ring_width <= 0 || g->n_cols < 0 || g->x_wrap <= 0 ||
         g->n_colors <= 0 || g->col_first < 0 || g->x_first < 0 || (!g->argb_out && !g->index_out))
         return jsg_fail(JSG_ERR_INVALID, "jsg_colormap_launch: bad geometry");
     if (g->n_cols > g->ring_width)
@@ -1221,6 +1311,8 @@ int jsg_colormap_launch(const jsg_colormap_args* g, void* stream) {
     ka.argb_pitch = g->argb_pitch;
     ka.index = g->index_out;
     ka.index_pitch = g->index_pitch;
+    ka.idx_in = idx_in;
+    ka.idx_in_pitch = idx_in_pitch;
     dim3 grid((g->n_cols + CM_TILE - 1) / CM_TILE, (g->height + CM_TILE - 1) / CM_TILE);
     hipLaunchKernelGGL(colormap_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ka);
     hipError_t err = hipGetLastError();

@@ -331,6 +331,53 @@ def colormap(d_db, d_lut, lo: float, hi: float, *, d_argb=None, d_index=None, co
     check(lib().jsg_colormap_launch(C.byref(a), C.c_void_p(stream)))
 
 
+def stft_image(plan: Plan, d_in, hop: int, n_frames: int, d_lut, lo: float, hi: float, d_argb, d_index_scratch, *,
+               feedblocks: int | None = None, mix_mode: int = 0, first_frame: int = 0, ring_pos: int = 0, ring_width: int | None = None,
+               x_first: int | None = None, stream: int | None = None):
+    """Fused display path (jsg_stft_image_launch): STFT -> 8-bit palette index columns (d_index_scratch, uint8
+    [ring_width][pitch >= n/2+1]) -> ARGB rows of d_argb [n/2+1][Wimg]; no dB column is written.  The image equals
+    stft_db() + colormap() bit for bit."""
+    import torch
+    assert d_index_scratch.is_cuda and d_index_scratch.dtype == torch.uint8 and d_index_scratch.dim() == 2 and d_index_scratch.stride(1) == 1
+    assert d_argb.is_cuda and d_argb.element_size() == 4 and d_argb.dim() == 2 and d_argb.stride(1) == 1
+    W = ring_width if ring_width is not None else d_index_scratch.shape[0]
+    a = capi.StftImageArgs()
+    dummy = torch.empty((W, 0), dtype=torch.float32, device=d_in.device)   # geometry only: out_db stays NULL
+    H = plan.n // 2 + 1
+    st = capi.StftArgs()
+    st.in_ = d_in.data_ptr()
+    st.in_pitch = d_in.stride(0) if d_in.shape[0] > 1 else d_in.shape[1]
+    st.in_samples = d_in.shape[1]
+    st.channels = d_in.shape[0]
+    st.hop = hop
+    st.feedblocks = feedblocks if feedblocks is not None else max(1, plan.n // hop)
+    st.mix_mode = mix_mode
+    st.first_frame = first_frame
+    st.n_frames = n_frames
+    st.ring_width = W
+    st.ring_pos = ring_pos
+    del dummy
+    a.stft = st
+    c = capi.ColormapArgs()
+    c.ring_width = W
+    c.height = H
+    c.col_first = ring_pos
+    c.n_cols = n_frames
+    c.x_first = ring_pos if x_first is None else x_first
+    c.x_wrap = d_argb.shape[1]
+    c.lut = d_lut.data_ptr()
+    c.n_colors = d_lut.numel()
+    c.vmin, c.vmax, c.access_mult = (float(v) for v in colormap_range(c.n_colors, lo, hi))
+    c.argb_out = d_argb.data_ptr()
+    c.argb_pitch = d_argb.stride(0)
+    a.colour = c
+    a.index_scratch = d_index_scratch.data_ptr()
+    a.index_scratch_pitch = d_index_scratch.stride(0)
+    if stream is None:
+        stream = torch.cuda.current_stream(d_in.device).cuda_stream
+    check(lib().jsg_stft_image_launch(plan._p, C.byref(a), C.c_void_p(stream)))
+
+
 def db_from_power(d_power, d_out, divisor: float = 1.0, stream: int | None = None):
     """out = 10*log10(power/divisor + 1e-11f) elementwise on the GPU (finishes a cross-GPU AbsMean)."""
     import torch

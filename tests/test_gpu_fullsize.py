@@ -172,6 +172,53 @@ def test_c5_stereo_96k_4096_with_colormap(jsg, oracle, torch_cuda):
     assert (d_idx.cpu().numpy() == ref_idx).all()
 
 
+def test_c5_fused_image_equals_two_kernel_image(jsg, oracle, torch_cuda):
+    """the fused display path (STFT epilogue -> 8-bit palette index -> ARGB; no dB column in memory)
+    must give the image of stft_db + colormap bit for bit on the C5 workload."""
+    torch = torch_cuda
+    n, hop, F, C = 4096, 512, 1875, 2
+    plan = jsg.Plan(n, oracle.window(oracle.WIN_HANN, n))
+    d_in = _stream(torch, C, F * hop + n - hop, seed=9)
+    H = n // 2 + 1
+    d_db = torch.empty((F, 2080), device="cuda")
+    d_lut = torch.from_numpy(jsg.colormap_lut(256, jsg.capi.CM_JADE)).cuda()
+    pos = 123   # ring position of the first column / image x of the first column: both wrap inside the launch
+    two = torch.zeros((H, 1888), dtype=torch.int32, device="cuda")      # rows padded to 32 pixels like the engine's image
+    jsg.stft_db(plan, d_in, hop, F, d_db, feedblocks=8, ring_pos=pos)
+    jsg.colormap(d_db, d_lut, -50.0, 50.0, d_argb=two[:, :F], col_first=pos, x_first=pos, height=H)
+    fused = torch.zeros_like(two)
+    scratch = torch.zeros((F, 2112), dtype=torch.uint8, device="cuda")
+    jsg.stft_image(plan, d_in, hop, F, d_lut, -50.0, 50.0, fused[:, :F], scratch, feedblocks=8, ring_pos=pos)
+    torch.cuda.synchronize()
+    assert torch.equal(fused, two)
+    # and the scratch holds exactly the oracle's palette index of the GPU's own dB values
+    pal = oracle.OracleColorPalette(256, oracle.CM_JADE); pal.set_value_range(-50.0, 50.0)
+    assert (scratch[:, :H].cpu().numpy() == pal.index(d_db[:, :H].cpu().numpy()).astype(np.uint8)).all()
+
+
+@pytest.mark.parametrize("n,channels,mix,lo,hi,scheme", [(1024, 1, 0, -50.0, 50.0, 6), (512, 2, 0, -110.0, 0.0, 4), (2048, 3, 0, 20.0, -80.0, 2),
+                                                          (8192, 2, 3, -50.0, 50.0, 6), (1024, 2, 4, 10.0, 10.0, 1)])
+def test_fused_image_every_plan(jsg, oracle, torch_cuda, n, channels, mix, lo, hi, scheme):
+    torch = torch_cuda
+    hop, F = n // 4, 300
+    plan = jsg.Plan(n, oracle.window(oracle.WIN_HANN, n))
+    d_in = _stream(torch, channels, (F - 1) * hop + n, seed=n + channels)
+    H = n // 2 + 1
+    pitch = (H + 31) // 32 * 32
+    d_db = torch.empty((F, pitch), device="cuda")
+    d_lut = torch.from_numpy(jsg.colormap_lut(256, scheme)).cuda()
+    two = torch.zeros((H, F), dtype=torch.int32, device="cuda")
+    jsg.stft_db(plan, d_in, hop, F, d_db, feedblocks=4, mix_mode=mix)
+    jsg.colormap(d_db, d_lut, lo, hi, d_argb=two, height=H)
+    fused = torch.zeros_like(two)
+    scratch = torch.zeros((F, (H + 63) // 64 * 64), dtype=torch.uint8, device="cuda")
+    jsg.stft_image(plan, d_in, hop, F, d_lut, lo, hi, fused, scratch, feedblocks=4, mix_mode=mix)
+    torch.cuda.synchronize()
+    assert torch.equal(fused, two)
+    with pytest.raises(jsg.JsgError):      # Max / Min mixes and tables of more than 256 colours take the two-kernel path
+        jsg.stft_image(plan, d_in, hop, F, d_lut, lo, hi, fused, scratch, feedblocks=4, mix_mode=1)
+
+
 @pytest.mark.parametrize("n,F", [(4096, 9000), (8192, 5000), (2048, 20000), (512, 40000)])
 def test_persistent_loop_of_every_plan(jsg, oracle, torch_cuda, n, F):
     """Launches large enough that every workgroup loops over several frames (iters > 1), incl. the plans whose frames

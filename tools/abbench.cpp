@@ -83,7 +83,7 @@ struct Lib {
     int (*cmap_range)(int, float, float, float*, float*, float*) = nullptr;
     const char* (*last_error)(const void*) = nullptr;
     // optional (newer builds): fused STFT -> colour launch
-    int (*stft_image)(const jsg_plan*, const jsg_stft_args*, const void*, void*) = nullptr;
+    int (*stft_image)(const jsg_plan*, const jsg_stft_image_args*, void*) = nullptr;
     void (*set_stamps)(void*) = nullptr;   // development builds (-DJSG_DEV_VARIANTS -DJSG_X_ABL=3)
 };
 
@@ -209,11 +209,14 @@ int main(int argc, char** argv) {
             }
         std::vector<float*> d_in(nbuf), d_out(nbuf);
         std::vector<uint32_t*> d_img(nbuf, nullptr);
+        std::vector<uint8_t*> d_idx(nbuf, nullptr);
+        const int64_t idx_pitch = (H + 63) / 64 * 64;
         for (int b = 0; b < nbuf; ++b) {
             CK(hipMalloc(reinterpret_cast<void**>(&d_in[b]), in_bytes));
             CK(hipMalloc(reinterpret_cast<void**>(&d_out[b]), out_bytes));
             CK(hipMemcpy(d_in[b], hx.data(), in_bytes, hipMemcpyHostToDevice));
             if (c.colour) CK(hipMalloc(reinterpret_cast<void**>(&d_img[b]), img_bytes));
+            if (c.colour) CK(hipMalloc(reinterpret_cast<void**>(&d_idx[b]), size_t(c.frames) * idx_pitch));
         }
         int32_t* d_lut = nullptr;
         CK(hipMalloc(reinterpret_cast<void**>(&d_lut), 256 * 4));
@@ -335,6 +338,25 @@ int main(int argc, char** argv) {
                 CK(hipMemcpy(got.data(), d_out[b], out_bytes, hipMemcpyDeviceToHost));
                 if (c.colour) CK(hipMemcpy(got_img.data(), d_img[b], img_bytes, hipMemcpyDeviceToHost));
             }
+            if (c.colour && l.stft_image) {   // fused image of this library against its own two-kernel image
+                std::vector<uint32_t> fimg(got_img.size());
+                CK(hipMemset(d_img[1], 0, img_bytes));
+                jsg_stft_image_args fa{};
+                fa.stft = args_for(1);
+                fa.stft.in = d_in[0];
+                fa.stft.out_db = nullptr;
+                fa.colour = ca;
+                fa.colour.argb_out = d_img[1];
+                fa.index_scratch = d_idx[1];
+                fa.index_scratch_pitch = idx_pitch;
+                if (l.stft_image(plans[li], &fa, one) != 0) std::fprintf(stderr, "fused launch failed: %s\n", l.last_error(nullptr));
+                CK(hipStreamSynchronize(one));
+                CK(hipMemcpy(fimg.data(), d_img[1], img_bytes, hipMemcpyDeviceToHost));
+                size_t px = 0;
+                for (int y = 0; y < H; ++y)
+                    for (int x = 0; x < c.frames; ++x) px += fimg[size_t(y) * img_pitch + x] != got_img[size_t(y) * img_pitch + x];
+                std::printf("   %-40s fused image vs two-kernel image: %zu differing pixels of %zu\n", l.path.c_str(), px, size_t(H) * c.frames);
+            }
             if (li == 0) {
                 ref_out = got;
                 ref_img = got_img;
@@ -418,10 +440,15 @@ int main(int argc, char** argv) {
                 const int b = i % nbuf;
                 jsg_stft_args a = args_for(b);
                 if (fused) {
-                    jsg_colormap_args cc = ca;
-                    cc.db = nullptr;
-                    cc.argb_out = d_img[b];
-                    l.stft_image(plans[li], &a, &cc, one);
+                    jsg_stft_image_args fa{};
+                    fa.stft = a;
+                    fa.stft.out_db = nullptr;
+                    fa.colour = ca;
+                    fa.colour.db = nullptr;
+                    fa.colour.argb_out = d_img[b];
+                    fa.index_scratch = d_idx[b];
+                    fa.index_scratch_pitch = idx_pitch;
+                    l.stft_image(plans[li], &fa, one);
                 } else {
                     l.stft(plans[li], &a, one);
                     if (c.colour) {
@@ -500,6 +527,7 @@ int main(int argc, char** argv) {
             CK(hipFree(d_in[b]));
             CK(hipFree(d_out[b]));
             if (d_img[b]) CK(hipFree(d_img[b]));
+            if (d_idx[b]) CK(hipFree(d_idx[b]));
         }
         CK(hipFree(d_lut));
     }
