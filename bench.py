@@ -4,29 +4,65 @@
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
 torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
 
-A "step" is one launch of the fused STFT->dB kernel over one batch of BASELINE.json configs[1]:
-mono 48 kHz, 1024-point FFT, hop 512, Hann, 4096 frames per launch, input stream and dB ring resident in HBM.
-Every rank works on its own independent streams (weak scaling, no data-path collective: the path shards by
-channel/stream); RCCL is used only for the barriers and the max-over-ranks time.
+What a step is
+--------------
+A step is a FIXED, stated group of launches of the fused kernel over synthetic batches that are resident in HBM, so the
+result does not depend on how many steps the driver asks for:
 
-To keep the numbers honest against the 256 MiB Infinity Cache, the steps rotate over NBUF distinct input/output
-batches (> 256 MiB in total), so every launch streams its 8.4 MB in and 8.4 MB out from/to HBM.
+  c2 (default, BASELINE.json configs[1]): one step = 1024 launches x 4096 frames (mono 48 kHz, 1024-point FFT, hop 512,
+      Hann) = 4 194 304 frames.  The launches of a step are independent batches; they are issued by ONE C call
+      (jsg_stft_db_launch_many_threads) round-robin over 8 HIP streams, so the ramp-up and drain of one launch overlap
+      the others.  `value` = frames of all ranks / wall time of the K steps.
+  c3 (configs[2]): one step = 64 launches x 4096 columns of 8-channel 2048-point frames, 75 % overlap, AbsMean mix.
+  c5 (configs[4]): one step = 128 launches x 1875 columns, stereo 96 kHz, 4096-point FFT, 87.5 % overlap, fused
+      STFT -> palette index -> ARGB image (jsg_stft_image_launch).
+  c3 / c5 are replayed in order from a hipGraph (their launches fill the GPU on their own).
+
+The batches rotate over enough distinct buffers to exceed the 256 MiB Infinity Cache, so every launch streams from
+and to HBM.  Before the W warm-up steps the same launches run for about 0.3 s so that the clocks have settled.
+
+`roofline` is the per-kernel view: the same launches, one at a time in order on ONE stream (a hipGraph replay, timed
+with HIP events on that stream); achieved = algorithmic bytes per launch / average launch duration.  rocprofv3's
+per-dispatch duration of `bench.py --streams 1` (profiles/) is the cross-check.
+
+Every rank works on its own batches (weak scaling; the path shards by channel / stream, there is no data-path
+collective); RCCL carries only the barriers and the max-over-ranks time.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_FFT, HOP, FRAMES = 1024, 512, 4096
-H = N_FFT // 2 + 1
-ALGO_BYTES_PER_FRAME = 4 * HOP + 4 * H          # SURVEY section 8d: input counted once + one dB column = 4100 B
-HBM_PEAK_GBS = 8000.0                           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6300.0  # ... and about 6.3 TB/s achievable (measured streaming copy)
+
+# name -> workload (SURVEY section 8d: algorithmic bytes count every input sample once and every output value once)
+CONFIGS = {
+    "c2": dict(n=1024, hop=512, channels=1, frames=4096, fs=48000.0, colour=False, launches_per_step=1024, streams=8,
+               metric="STFT frames/sec (1024-pt, 50% hop)", unit="frames/s",
+               workload="configs[1]: mono 48 kHz, 1024-pt FFT, 512 hop, Hann, 4096 frames/launch, input + dB ring resident in HBM"),
+    "c3": dict(n=2048, hop=512, channels=8, frames=4096, fs=48000.0, colour=False, launches_per_step=64, streams=1,
+               metric="STFT frames/sec (2048-pt, 75% overlap, 8 channels mixed to one column)", unit="frames/s",
+               workload="configs[2]: 8-channel 48 kHz, 2048-pt FFT, 512 hop (75 % overlap), Hann, AbsMean mix, 4096 columns/launch"),
+    "c5": dict(n=4096, hop=512, channels=2, frames=1875, fs=96000.0, colour=True, launches_per_step=128, streams=1,
+               metric="STFT->ARGB columns/sec (4096-pt, 87.5% overlap, stereo 96 kHz)", unit="columns/s",
+               workload="configs[4]: stereo 96 kHz, 4096-pt FFT, 512 hop (87.5 % overlap), AbsMean, Jade LUT -50..50 dB -> ARGB image, "
+                        "1875 columns (10 s) per launch, fused STFT -> palette index -> ARGB"),
+}
+
+
+def algorithmic_bytes_per_launch(c) -> int:
+    H = c["n"] // 2 + 1
+    per_column = 4 * c["hop"] * c["channels"] + (4 * H if c["colour"] else 4 * H)   # input once + one dB column, or one ARGB column
+    return per_column * c["frames"]
 
 
 def synth_audio(channels: int, n_samples: int, fs: float = 48000.0, seed: int = 1234):
@@ -51,70 +87,145 @@ def _cpu_model() -> str:
     return "unknown"
 
 
-def cpu_baseline(seconds_budget: float = 12.0, check=None):
-    """The oracle's CPU path timed on this host (rank 0, N=1 only): reported baseline, not the target.
-    This leg is the only place where bench.py touches oracle/ (test infrastructure); `check` = (samples, dB) of a few
-    frames the GPU just produced, compared against the oracle before timing it."""
+def _git_commit() -> str:
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        pass
+    try:   # the GPU box has no .git: the build step left a note next to the library it built
+        return json.load(open(os.path.join(ROOT, "jadespectrogram_amd", "_build_info.json"))).get("commit", "unknown") + " (build)"
+    except Exception:
+        return "unknown"
+
+
+def cpu_baseline(c, seconds_budget: float = 10.0):
+    """The oracle's CPU path (oracle/jsg_oracle_c.c, a scalar float32 C port of Spectrogram::processSynchronBlock, plus
+    CColorPalette::getRGBColor for c5) timed on this host -- rank 0, N = 1 only.  A reported baseline, not the target.
+    This leg and parity_report() are the only places where bench.py touches oracle/ (test infrastructure)."""
     import numpy as np
     from oracle import jsg_oracle as oracle
-    try:
-        from oracle import oracle_c
-        port = oracle_c.load()
-    except Exception:
-        port = None
-    win = oracle.window(oracle.WIN_HANN, N_FFT)
-    if check is not None:
-        x, got = check
-        fr = np.stack([x[j * HOP:j * HOP + N_FFT] * win for j in range(got.shape[0])]).astype(np.float32)
-        assert np.abs(got - oracle.to_db(oracle.power_spectrum(fr))).max() < 5e-3, "bench output drifted from the oracle"
-    if port is not None:
-        frames = 20000
-        x = synth_audio(1, frames * HOP + N_FFT)
-        t0 = time.perf_counter(); done = 0
-        while time.perf_counter() - t0 < seconds_budget:
-            port.stft_db(x, N_FFT, HOP, frames, win)
-            done += frames
-        dt = time.perf_counter() - t0
-        res = {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": f"{done} frames of the bench workload through oracle/jsg_oracle_c.c (scalar float32 C port "
-                         f"of Spectrogram::processSynchronBlock, 1 thread) in {dt:.1f} s",
-               "cpu_model": _cpu_model()}
-        # the same port with OpenMP over frames on every core this process may use (SURVEY 8d: 1 thread and all cores)
-        cores = min(len(os.sched_getaffinity(0)), 64)
-        if cores > 1:
-            t0 = time.perf_counter(); done = 0
-            while time.perf_counter() - t0 < seconds_budget / 3:
-                port.stft_db(x, N_FFT, HOP, frames, win, threads=cores)
-                done += frames
-            dt = time.perf_counter() - t0
-            res["all_cores"] = {"value": done / dt, "unit": "frames/s", "cores": cores,
-                                "sample": f"{done} frames, OpenMP over frames, in {dt:.1f} s"}
-        return res
-    frames = 8192
-    x = synth_audio(1, frames * HOP + N_FFT)
-    t0 = time.perf_counter(); done = 0
-    while time.perf_counter() - t0 < seconds_budget:
-        oracle.stft_db_reference(x[:, N_FFT:], N_FFT, HOP, 2, win)
-        done += (x.shape[1] - N_FFT) // N_FFT * 2
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{done} frames through oracle/jsg_oracle.py (numpy float64 rfft restatement) in {dt:.1f} s"}
+    from oracle import oracle_c
+    port = oracle_c.load()
+    n, hop, C = c["n"], c["hop"], c["channels"]
+    win = oracle.window(oracle.WIN_HANN, n)
+    fb = n // hop
+    units_per_col = 1 if c["colour"] else C          # frames (FFTs) for c2/c3, columns for c5
+    cols = max(256, min(20000, int(1.5e5 * 1024 / n / C)))
+    x = synth_audio(C, cols * hop + n, fs=c["fs"])
+    out = np.empty((cols, n // 2 + 1), np.float32)
+    pal = lut = None
+    if c["colour"]:
+        pal = oracle.OracleColorPalette(256, oracle.CM_JADE)
+        pal.set_value_range(-50.0, 50.0)
+        lut = oracle.compute_colors(256, oracle.CM_JADE)
+
+    def once(threads):
+        port.stft_db(x, n, hop, cols, win, feedblocks=fb, mix=0, threads=threads, out=out)
+        if c["colour"]:
+            port.colour_columns(out, lut, float(pal.vmin), float(pal.vmax), float(pal.mult), threads=threads)
+
+    def timed(threads, budget):
+        once(threads)                                 # page in, build the plan
+        rates = []
+        t_end = time.perf_counter() + budget
+        while time.perf_counter() < t_end or len(rates) < 3:
+            t0 = time.perf_counter()
+            once(threads)
+            rates.append(cols * units_per_col / (time.perf_counter() - t0))
+        return float(np.median(rates)), len(rates)
+
+    v1, k1 = timed(1, seconds_budget)
+    res = {"value": v1, "unit": c["unit"], "cores": 1, "kind": "port",
+           "sample": f"median of {k1} passes over {cols} columns ({cols * C} FFTs) of the bench workload through oracle/jsg_oracle_c.c "
+                     f"(scalar float32 C port of Spectrogram::processSynchronBlock{' + getRGBColor' if c['colour'] else ''}), 1 thread, "
+                     f"about {seconds_budget:.0f} s",
+           "cpu_model": _cpu_model()}
+    cores = min(len(os.sched_getaffinity(0)), 64)
+    if cores > 1:
+        v2, k2 = timed(cores, seconds_budget / 3)
+        res["all_cores"] = {"value": v2, "unit": c["unit"], "cores": cores,
+                            "sample": f"median of {k2} passes, OpenMP over columns, plan and buffers reused across passes"}
+    return res
+
+
+def parity_report(jsg, c, plan, d_in_host, win):
+    """What the tolerances of the parity tests mean on THIS workload (rank 0, N = 1): the share of bins whose relative
+    power error against the float64 DFT exceeds plain 1e-5 and how far below their frame's peak they sit; and the number
+    of colour indices that differ end to end (GPU power -> GPU dB -> GPU index against oracle power -> oracle dB -> oracle
+    index) with the default Jade/256/(-50,50) palette.  Checker code: oracle/ (test infrastructure)."""
+    import numpy as np
+    import torch
+    from oracle import jsg_oracle as oracle
+    n, hop, C = c["n"], c["hop"], c["channels"]
+    H = n // 2 + 1
+    F = min(c["frames"], 512)
+    x = d_in_host[:, :(F - 1) * hop + n]
+    d_x = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    pitch = (H + 31) // 32 * 32
+    d_pow = torch.empty((F, pitch), dtype=torch.float32, device="cuda")
+    mix = jsg.capi.MIX_ABSMEAN
+    jsg.stft_db(plan, d_x, hop, F, d_pow, feedblocks=n // hop, mix_mode=mix, linear_out=True)
+    d_db = torch.empty((F, pitch), dtype=torch.float32, device="cuda")
+    jsg.stft_db(plan, d_x, hop, F, d_db, feedblocks=n // hop, mix_mode=mix)
+    d_lut = torch.from_numpy(jsg.colormap_lut(256, jsg.capi.CM_JADE)).cuda()
+    d_img = torch.zeros((H, F), dtype=torch.int32, device="cuda")
+    d_scr = torch.zeros((F, (H + 63) // 64 * 64), dtype=torch.uint8, device="cuda")
+    jsg.stft_image(plan, d_x, hop, F, d_lut, -50.0, 50.0, d_img, d_scr, feedblocks=n // hop, mix_mode=mix)
+    torch.cuda.synchronize()
+    got_p = d_pow[:, :H].cpu().numpy().astype(np.float64)
+    got_idx = d_scr[:, :H].cpu().numpy()
+    idx = (np.arange(F) * hop)[:, None] + np.arange(n)[None, :]
+    frames = (x[:, idx] * win[None, None, :]).astype(np.float32)                       # [C][F][n]
+    p64 = oracle.power_spectrum_f64(frames)                                            # float64 DFT of the float32 frames
+    ref_mixed32 = oracle.mix_channels(p64.astype(np.float32), oracle.MIX_ABSMEAN)      # the reference's float32 channel mix
+    ref_p = ref_mixed32.astype(np.float64)
+    rel = np.abs(got_p - ref_p) / np.maximum(ref_p, 1e-300)
+    bad = rel > 1e-5
+    peak = ref_p.max(axis=1, keepdims=True)
+    level_db = 10.0 * np.log10(np.maximum(ref_p, 1e-300) / peak)
+    strong = ref_p > 1e-2 * peak
+    pal = oracle.OracleColorPalette(256, oracle.CM_JADE)
+    pal.set_value_range(-50.0, 50.0)
+    ref_idx = pal.index(oracle.to_db(ref_mixed32)).astype(np.uint8)
+    flips = int((got_idx != ref_idx).sum())
+    db_err = np.abs(d_db[:, :H].cpu().numpy().astype(np.float64) - oracle.to_db(ref_mixed32).astype(np.float64))
+    return {"frames_checked": int(F), "bins_checked": int(rel.size),
+            "frac_bins_rel_power_err_gt_1e-5": float(bad.mean()),
+            "those_bins_level_below_frame_peak_db": {"median": float(np.median(level_db[bad])) if bad.any() else None,
+                                                     "highest": float(level_db[bad].max()) if bad.any() else None},
+            "max_rel_power_err_bins_within_20dB_of_peak": float(rel[strong].max()),
+            "max_abs_db_err": float(db_err.max()),
+            "colour_index_flips_end_to_end": flips, "pixels_checked": int(got_idx.size),
+            "note": "float64 DFT of the float32 windowed frames is the yardstick; indices: Jade, 256 colours, -50..50 dB"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)
-    ap.add_argument("--warmup", type=int, default=2000)
-    ap.add_argument("--nbuf", type=int, default=24, help="distinct batches rotated through (24 x 16.8 MB > 256 MiB)")
-    ap.add_argument("--streams", type=int, default=8, help="HIP streams the independent launches are spread over")
-    ap.add_argument("--blocks-per-cu", type=int, default=1, help="workgroups per CU of each launch in the concurrent pass")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--launches-per-step", type=int, default=0, help="launches in one step (default: the configuration's)")
+    ap.add_argument("--nbuf", type=int, default=0, help="distinct batches rotated through (default: enough for > 256 MiB)")
+    ap.add_argument("--streams", type=int, default=0, help="HIP streams of the timed region (default: 8 for c2, 1 otherwise)")
+    ap.add_argument("--issue-threads", type=int, default=2, help="host threads issuing the launches of a step (c2, streams > 1)")
+    ap.add_argument("--blocks-per-cu", type=int, default=1, help="workgroups per CU of each launch when launches overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work at all: exercises the N-rank plumbing (barriers, reductions, "
+                                                           "JSON) on a machine without GPUs; value is null")
     args = ap.parse_args()
+    c = dict(CONFIGS[args.config])
+    lps = args.launches_per_step or c["launches_per_step"]
+    n_streams = max(1, args.streams or c["streams"])
 
     import numpy as np
     import torch
-    import jadespectrogram_amd as jsg
+
+    # child processes (git, and make if the C oracle is stale) are started BEFORE anything initialises the GPU
+    commit = _git_commit()
+    if not args.dry_run and not args.no_cpu_baseline:
+        from oracle import oracle_c
+        oracle_c.load()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -123,11 +234,13 @@ def main():
         assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     # JSG_BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks (ranks then share devices);
     # the driver's runs use the default: one rank per GPU, RCCL ("nccl") over xGMI
-    backend = os.environ.get("JSG_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(dev_index)
-    red_dev = "cuda" if backend == "nccl" else "cpu"
+    backend = "gloo" if args.dry_run else os.environ.get("JSG_BENCH_BACKEND", "nccl")
     dist = None
+    dev_index = 0
+    if not args.dry_run:
+        dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(dev_index)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -136,136 +249,214 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    # ---- workload: NBUF independent mono batches per rank, resident in HBM ----
-    win = jsg.window(jsg.capi.WIN_HANN, N_FFT)
-    plan = jsg.Plan(N_FFT, win)
-    n_samples = FRAMES * HOP + (N_FFT - HOP)
-    pitch = (H + 31) // 32 * 32
-    d_in, d_out = [], []
-    base = synth_audio(1, n_samples + args.nbuf * 64, seed=1234 + 1000 * rank)   # SURVEY 8d signal
-    for b in range(args.nbuf):
-        d_in.append(torch.from_numpy(np.ascontiguousarray(base[:, b * 64:b * 64 + n_samples])).cuda())
-        d_out.append(torch.empty((FRAMES, pitch), dtype=torch.float32, device="cuda"))
-    # The K steps of the timed region are K independent launches (step i works on batch i % nbuf).  They are issued
-    # by ONE C call (jsg_stft_db_launch_many: no per-step FFI cost) round-robin on `n_streams` HIP streams, so the
-    # dispatch ramp / first-data latency / store drain of one launch overlap the compute of the others.  A second
-    # pass issues the same K steps in order on a single stream: that is the classic per-kernel view used for
-    # `roofline` (HIP events on the stream the kernel runs on; agrees with rocprofv3's per-dispatch duration).
-    import ctypes
-    from jadespectrogram_amd import capi
-    from jadespectrogram_amd.spectrogram import _stft_args
-    lib = capi.lib()
-    n_streams = max(1, args.streams)
-    while args.nbuf % n_streams:        # a batch must always land on the same stream (its ring is rewritten in order)
-        n_streams -= 1
-    total = max(args.steps, args.warmup)
-    # concurrent pass: one workgroup per CU, two frames per wavefront with prefetch (fewer, longer-lived workgroups
-    # overlap better across launches); in-order pass: the default geometry (best for one launch alone)
-    arr = (capi.StftArgs * total)()
-    arr_inorder = (capi.StftArgs * total)()
-    for i in range(total):
-        for dst_arr, bpc in ((arr, args.blocks_per_cu if n_streams > 1 else 0), (arr_inorder, 0)):
-            a_i = _stft_args(plan, d_in[i % args.nbuf], HOP, FRAMES, d_out[i % args.nbuf], feedblocks=2, blocks_per_cu=bpc)
-            ctypes.memmove(ctypes.byref(dst_arr, i * ctypes.sizeof(capi.StftArgs)), ctypes.byref(a_i), ctypes.sizeof(capi.StftArgs))
-    streams = [torch.cuda.Stream() for _ in range(n_streams)]
-    sarr = (ctypes.c_void_p * n_streams)(*[st.cuda_stream for st in streams])
-    one = torch.cuda.Stream()
-    one_arr = (ctypes.c_void_p * 1)(one.cuda_stream)
-
-    def run(count, handles, n, which=None):
-        capi.check(lib.jsg_stft_db_launch_many(plan._p, which if which is not None else arr, count, handles, n))
-
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    torch.cuda.synchronize()
-    run(args.warmup, sarr, n_streams)                       # W untimed warm-up steps
-    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    def sync():
+        if not args.dry_run:
+            torch.cuda.synchronize()
+
+    n, hop, C, F = c["n"], c["hop"], c["channels"], c["frames"]
+    H = n // 2 + 1
+    algo = algorithmic_bytes_per_launch(c)
+    units_per_launch = F if c["colour"] else F * C     # columns for c5, frames (FFTs) otherwise
+
+    run_step = None
+    inorder_us = eager_us = None
+    copy_us = None
+    parity = None
+    nbuf = 0
+    if not args.dry_run:
+        import jadespectrogram_amd as jsg
+        from jadespectrogram_amd import capi
+        from jadespectrogram_amd.spectrogram import _stft_args
+        lib = capi.lib()
+        win = jsg.window(jsg.capi.WIN_HANN, n)
+        plan = jsg.Plan(n, win)
+        n_samples = F * hop + (n - hop)
+        pitch = (H + 31) // 32 * 32
+        idx_pitch = (H + 63) // 64 * 64
+        img_pitch = (F + 31) // 32 * 32
+        per_batch = C * n_samples * 4 + (F * idx_pitch + H * img_pitch * 4 if c["colour"] else F * pitch * 4)
+        nbuf = args.nbuf or max(2, int(300e6 // per_batch) + 1)
+        while n_streams > 1 and nbuf % n_streams:   # a batch must always land on the same stream (its ring is rewritten in order)
+            nbuf += 1
+        base = synth_audio(C, n_samples + nbuf * 64, fs=c["fs"], seed=1234 + 1000 * rank)   # SURVEY 8d signal
+        d_in, d_out, d_img, d_scr = [], [], [], []
+        for b in range(nbuf):
+            d_in.append(torch.from_numpy(np.ascontiguousarray(base[:, b * 64:b * 64 + n_samples])).cuda())
+            if c["colour"]:
+                d_img.append(torch.zeros((H, img_pitch), dtype=torch.int32, device="cuda"))
+                d_scr.append(torch.zeros((F, idx_pitch), dtype=torch.uint8, device="cuda"))
+            else:
+                d_out.append(torch.empty((F, pitch), dtype=torch.float32, device="cuda"))
+        d_lut = torch.from_numpy(jsg.colormap_lut(256, jsg.capi.CM_JADE)).cuda() if c["colour"] else None
+        fb = n // hop
+        one = torch.cuda.Stream()
+
+        def launch(b, stream_handle, bpc=0):
+            if c["colour"]:
+                jsg.stft_image(plan, d_in[b], hop, F, d_lut, -50.0, 50.0, d_img[b][:, :F], d_scr[b], feedblocks=fb,
+                               mix_mode=jsg.capi.MIX_ABSMEAN, stream=stream_handle)
+            else:
+                jsg.stft_db(plan, d_in[b], hop, F, d_out[b], feedblocks=fb, mix_mode=jsg.capi.MIX_ABSMEAN, blocks_per_cu=bpc,
+                            stream=stream_handle)
+
+        # ---- the in-order group of one step as a hipGraph on ONE stream (per-kernel view; the timed region of c3 / c5) ----
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(one):
+            for b in range(min(nbuf, lps)):
+                launch(b, one.cuda_stream)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, stream=one):
+                for i in range(lps):
+                    launch(i % nbuf, one.cuda_stream)
+        torch.cuda.synchronize()
+
+        def replay_inorder():
+            with torch.cuda.stream(one):
+                graph.replay()
+
+        if n_streams > 1:
+            # ---- the overlapped group: lps independent launches from ONE C call over n_streams streams ----
+            arr = (capi.StftArgs * lps)()
+            for i in range(lps):
+                a_i = _stft_args(plan, d_in[i % nbuf], hop, F, d_out[i % nbuf], feedblocks=fb, mix_mode=jsg.capi.MIX_ABSMEAN,
+                                 blocks_per_cu=args.blocks_per_cu)
+                ctypes.memmove(ctypes.byref(arr, i * ctypes.sizeof(capi.StftArgs)), ctypes.byref(a_i), ctypes.sizeof(capi.StftArgs))
+            streams = [torch.cuda.Stream() for _ in range(n_streams)]
+            sarr = (ctypes.c_void_p * n_streams)(*[st.cuda_stream for st in streams])
+
+            def run_step():
+                capi.check(lib.jsg_stft_db_launch_many_threads(plan._p, arr, lps, sarr, n_streams, max(1, args.issue_threads)))
+        else:
+            run_step = replay_inorder
+    else:
+        def run_step():
+            time.sleep(0.001)
+
+    # ---- settle the clocks (about 0.3 s of the same work), W warm-up steps, then EXACTLY K timed steps ----
+    prewarm_s = 0.0
+    if not args.dry_run:
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < 0.3:
+            run_step()
+            sync()
+        prewarm_s = time.perf_counter() - t_pre
+    for _ in range(args.warmup):
+        run_step()
+    sync(); barrier(); sync()
     t0 = time.perf_counter()
-    run(args.steps, sarr, n_streams)                        # EXACTLY K timed steps
-    torch.cuda.synchronize()
+    for _ in range(args.steps):
+        run_step()
+    sync()
     t1 = time.perf_counter()
-    barrier(); torch.cuda.synchronize()
+    barrier(); sync()
     wall = t1 - t0
 
-    # in-order pass for the per-kernel roofline (not part of `value`)
-    run(min(args.warmup, 50), one_arr, 1, arr_inorder)
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record(one)
-    run(args.steps, one_arr, 1, arr_inorder)
-    ev1.record(one)
-    torch.cuda.synchronize()
-    ev_ms = ev0.elapsed_time(ev1)                       # events on the stream the kernel runs on
-    barrier(); torch.cuda.synchronize()
+    if not args.dry_run:
+        # ---- per-kernel view: the same launches in order on one stream, HIP events on that stream ----
+        reps = max(3, min(args.steps, 20))
+        replay_inorder(); torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(one):
+            ev0.record(one)
+            for _ in range(reps):
+                graph.replay()
+            ev1.record(one)
+        torch.cuda.synchronize()
+        inorder_us = ev0.elapsed_time(ev1) * 1e3 / (reps * lps)
+        if not c["colour"]:   # host-issued launches on the same stream, for comparison (adds the runtime's per-launch handling)
+            k = min(lps, 512)
+            with torch.cuda.stream(one):
+                for i in range(64):
+                    launch(i % nbuf, one.cuda_stream)
+                torch.cuda.synchronize()
+                ev0.record(one)
+                for i in range(k):
+                    launch(i % nbuf, one.cuda_stream)
+                ev1.record(one)
+            torch.cuda.synchronize()
+            eager_us = ev0.elapsed_time(ev1) * 1e3 / k
+    barrier(); sync()
     if dist is not None:
-        t = torch.tensor([wall, ev_ms], dtype=torch.float64, device=red_dev)
+        t = torch.tensor([wall, inorder_us or 0.0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, ev_ms = float(t[0]), float(t[1])
+        wall, inorder_us = float(t[0]), (float(t[1]) or None)
 
-    # what was just timed, for the parity spot check inside the cpu_baseline leg
-    check = None
-    if rank == 0:
-        b = (args.steps - 1) % args.nbuf
-        check = (d_in[b][0, :N_FFT + 3 * HOP].cpu().numpy(), d_out[b][:4, :H].cpu().numpy())
-
-    # context for the roofline: a plain device-to-device copy of the SAME byte count (8.4 MB in, 8.4 MB out per launch),
-    # rotating over the same number of distinct buffers -- what this launch size can reach at all on this GPU
-    copy_us = None
-    if rank == 0:
-        nflt = ALGO_BYTES_PER_FRAME * FRAMES // 8
-        csrc = [torch.rand(nflt, device="cuda") for _ in range(args.nbuf)]
-        cdst = [torch.empty(nflt, device="cuda") for _ in range(args.nbuf)]
-        for i in range(50):
-            cdst[i % args.nbuf].copy_(csrc[i % args.nbuf])
+    if rank == 0 and not args.dry_run:
+        # context for the roofline: a plain device-to-device copy of the SAME byte count, same rotation, same graph timing --
+        # what a launch of this size can reach at all on this GPU
+        nflt = algo // 8
+        csrc = [torch.rand(nflt, device="cuda") for _ in range(nbuf)]
+        cdst = [torch.empty(nflt, device="cuda") for _ in range(nbuf)]
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(one):
+            cdst[0].copy_(csrc[0]); torch.cuda.synchronize()
+            with torch.cuda.graph(g2, stream=one):
+                for i in range(min(lps, 256)):
+                    cdst[i % nbuf].copy_(csrc[i % nbuf])
+            g2.replay(); torch.cuda.synchronize()
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record(one)
+            for _ in range(4):
+                g2.replay()
+            c1.record(one)
         torch.cuda.synchronize()
-        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        c0.record()
-        for i in range(500):
-            cdst[i % args.nbuf].copy_(csrc[i % args.nbuf])
-        c1.record()
-        torch.cuda.synchronize()
-        copy_us = c0.elapsed_time(c1) * 1e3 / 500
-        del csrc, cdst
+        copy_us = c0.elapsed_time(c1) * 1e3 / (4 * min(lps, 256))
+        del csrc, cdst, g2
+        if world == 1:
+            parity = parity_report(jsg, c, plan, base, win)
 
-    frames_total = world * args.steps * FRAMES
-    # per-kernel view: HIP events over the K in-order launches on one stream (rocprofv3's per-dispatch duration,
-    # profiles/r01_kernel_stats.csv, reads ~0.5 us longer: the tracer runs the dispatches isolated)
-    kernel_s = ev_ms * 1e-3 / args.steps
-    achieved = ALGO_BYTES_PER_FRAME * FRAMES / kernel_s / 1e9
-    traffic, rocprof_us = None, None
-    prof = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if os.path.exists(prof):
-        try:
-            pj = json.load(open(prof))
-            traffic = pj.get("hbm_bytes_per_launch")            # PMC FETCH_SIZE x2 (gfx950) + WRITE_SIZE, per launch
-            rocprof_us = pj.get("avg_ns", 0.0) / 1e3 or None    # rocprofv3 --kernel-trace --stats of this command
-        except Exception:
-            traffic = None
+    units_total = world * args.steps * lps * units_per_launch
     out = {
-        "metric": "STFT frames/sec (1024-pt, 50% hop)", "value": frames_total / wall, "unit": "frames/s",
+        "metric": c["metric"], "value": None if args.dry_run else units_total / wall, "unit": c["unit"],
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: mono 48 kHz, 1024-pt FFT, 512 hop, Hann, 4096 frames/launch, "
-                               "input+dB ring resident in HBM", "frames_per_launch": FRAMES, "channels_per_gpu": 1,
-                   "distinct_batches": args.nbuf, "hip_streams_per_gpu": n_streams,
+        "config": {"workload": c["workload"],
+                   "step": f"{lps} launches x {F} {'columns' if c['colour'] or C > 1 else 'frames'} = {lps * units_per_launch} {c['unit'].split('/')[0]} per step and GPU",
+                   "launches_per_step": lps, "frames_per_launch": F * C, "columns_per_launch": F, "channels_per_gpu": C,
+                   "distinct_batches": nbuf, "hip_streams_per_gpu": n_streams,
+                   "issue": ("hipGraph replay, in order" if n_streams == 1 else f"one C call per step, {max(1, args.issue_threads)} host thread(s)"),
+                   "prewarm_s": round(prewarm_s, 3),
                    "parallelism": f"{world} GPU(s), independent batches, no data-path collective"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "stft_db_kernel<1024>", "avg_launch_us": kernel_s * 1e6,
-                     "rocprof_isolated_dispatch_us": rocprof_us,
-                     "concurrent_achieved": ALGO_BYTES_PER_FRAME * FRAMES * args.steps / wall / 1e9,
-                     "concurrent_frac": ALGO_BYTES_PER_FRAME * FRAMES * args.steps / wall / 1e9 / HBM_PEAK_GBS,
-                     "note": "achieved/frac: one launch at a time on one stream; concurrent_*: the timed region itself "
-                             "(independent launches overlapped on hip_streams_per_gpu streams)",
-                     "memcpy_same_bytes_us": copy_us,
-                     "frac_of_memcpy_rate": (copy_us / (kernel_s * 1e6)) if copy_us else None,
-                     "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * FRAMES},
     }
+    if args.dry_run:
+        out["dry_run"] = True
+    if inorder_us:
+        achieved = algo / (inorder_us * 1e-6) / 1e9
+        conc = algo * lps * args.steps / wall / 1e9
+        traffic, tsrc = None, None
+        prof = os.path.join(ROOT, "profiles", f"r02_{args.config}_hbm_traffic.json")
+        if os.path.exists(prof):
+            try:
+                pj = json.load(open(prof))
+                traffic = pj.get("hbm_bytes_per_launch")
+                tsrc = {"file": os.path.relpath(prof, ROOT), "recorded_at_commit": pj.get("commit"), "rocprof_avg_dispatch_us": pj.get("avg_us"),
+                        "note": "PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE) recorded earlier with rocprofv3; NOT measured by this run"}
+            except Exception:
+                traffic = None
+        out["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "frac_of_8p0": achieved / HBM_PEAK_GBS, "frac_of_6p3": achieved / HBM_ACHIEVABLE_GBS,
+            "traffic": traffic, "traffic_source": tsrc,
+            "kernel": ("stft_db_kernel<4096, AbsMean, index out> + colormap_kernel (jsg_stft_image_launch)" if c["colour"]
+                       else f"stft_db_kernel<{n}>"),
+            "avg_launch_us": inorder_us, "avg_launch_us_host_issued": eager_us,
+            "how": f"HIP events on the launch stream around hipGraph replays of the step's {lps} launches, one at a time in order",
+            "algorithmic_bytes_per_launch": algo,
+            "timed_region_achieved": conc, "timed_region_frac_of_8p0": conc / HBM_PEAK_GBS, "timed_region_frac_of_6p3": conc / HBM_ACHIEVABLE_GBS,
+            "note": "achieved/frac: per-kernel view (in order, one stream); timed_region_*: algorithmic bytes of the K timed steps / their wall "
+                    "time (c2: launches overlapped on hip_streams_per_gpu streams)",
+            "memcpy_same_bytes_us": copy_us, "frac_of_memcpy_rate": (copy_us / inorder_us) if copy_us else None,
+            "commit": commit,
+        }
+    if parity is not None:
+        out["parity"] = parity
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(check=check)
+        if world == 1 and not args.no_cpu_baseline and not args.dry_run:
+            out["cpu_baseline"] = cpu_baseline(c)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

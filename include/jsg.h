@@ -143,6 +143,10 @@ int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* args, void* st
  * buffers): takes the per-launch FFI cost out of the caller's loop and, with more than one stream, lets the tail of
  * one launch overlap the ramp-up of the next.  Ordering between the streams is the caller's business. */
 int jsg_stft_db_launch_many(const jsg_plan* plan, const jsg_stft_args* args, int count, void* const* streams, int n_streams);
+/* The same issued by n_threads host threads (stream k belongs to thread k % n_threads, so the order inside a stream
+ * is kept): for callers whose single issuing thread (~3.5 us per launch) is slower than the GPU. */
+int jsg_stft_db_launch_many_threads(const jsg_plan* plan, const jsg_stft_args* args, int count, void* const* streams,
+                                    int n_streams, int n_threads);
 
 /* out[i] = 10*log10(power[i]/divisor + 1e-11f), i < count: the tail of the mix (reference Spectrogram.cpp:74,107)
  * for partial sums that were reduced across GPUs (JSG_MIX_SUM).  In place (out == power) is allowed. */

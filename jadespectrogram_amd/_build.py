@@ -72,11 +72,13 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(flavour_file) or open(flavour_file).read().strip() != flavour:
         force = True
     objs = []
+    recompiled, relinked = [], False
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
+            recompiled.append(src)
             cmd = [hipcc, "-std=c++17", "-O3", "-fPIC", "-c", s, "-o", o, "-I", os.path.join(ROOT, "include")]
             if src.endswith(".hip"):
                 # -fno-slp-vectorize: the kernel packs its complex arithmetic into v_pk_*_f32 by hand (re, im in one
@@ -92,12 +94,26 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
     if force or _stale(LIB, objs):
+        relinked = True
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
     with open(flavour_file, "w") as f:
         f.write(flavour + "\n")
+    # build record: what was compiled in this call and what was reused, for whoever reads the driver's log
+    import json, time
+    info = {"flavour": flavour, "recompiled": recompiled, "relinked": relinked, "lib_mtime": time.strftime("%Y-%m-%d %H:%M:%S", time.localtime(os.path.getmtime(LIB))),
+            "objects": {os.path.basename(o): time.strftime("%Y-%m-%d %H:%M:%S", time.localtime(os.path.getmtime(o))) for o in objs}}
+    try:
+        info["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+        info["dirty"] = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "jadespectrogram_amd", "include"],
+                                                     stderr=subprocess.DEVNULL).decode().strip())
+        with open(os.path.join(PKG, "_build_info.json"), "w") as f:   # travels with the snapshot (the GPU box has no .git)
+            json.dump(info, f)
+    except Exception:
+        pass
+    build_lib.last = info
     return LIB
 
 

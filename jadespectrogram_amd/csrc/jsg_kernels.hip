@@ -24,6 +24,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <new>
+#include <string>
+#include <thread>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -926,8 +928,9 @@ struct jsg_plan {
     size_t tab_elems = 0;
 };
 
-static unsigned long long* g_dev_stamps = nullptr;
+static unsigned long long* g_dev_stamps = nullptr;   // development builds: stamp buffer of the ABL == 3 variants
 
+#ifdef JSG_DEV_VARIANTS
 // development only: tuned streaming copy, the physical floor for "move these bytes once" at a given launch size
 template <bool NT>
 __global__ __launch_bounds__(256) void dev_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
@@ -958,8 +961,10 @@ static int occupancy_of(int* lds, int* threads) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stft_db_kernel<C, 3>, C::WPB * 64, C::LDS_BYTES) != hipSuccess) return -1;
     return nb;
 }
+#endif   // JSG_DEV_VARIANTS
 extern "C" {
 
+#ifdef JSG_DEV_VARIANTS
 // development only: the same copy with the STFT kernel's access widths (8-byte loads, 4-byte nt stores)
 __global__ __launch_bounds__(256) void dev_copy_narrow_kernel(const float2* __restrict__ src, float* __restrict__ dst, long long n2) {
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -1003,6 +1008,7 @@ int jsg_dev_occupancy(int n, int* lds, int* threads) {
     }
     return -1;
 }
+#endif   // JSG_DEV_VARIANTS (none of the jsg_dev_* entry points exists in the product library)
 
 int jsg_device_count(void) {
     int n = 0;
@@ -1265,6 +1271,36 @@ int jsg_stft_db_launch_many(const jsg_plan* plan, const jsg_stft_args* args, int
         const int rc = jsg_stft_db_launch(plan, &args[i], st);
         if (rc != JSG_OK) return rc;
     }
+    return JSG_OK;
+}
+
+// The same with `n_threads` host threads issuing: stream k is served by thread k % n_threads only, so the order inside every
+// stream is the order of `args`.  One thread issues a launch every ~3.5 us, which is about what eight overlapped
+// 4096-frame launches take on the GPU; a second thread takes the host out of the picture (tools/abbench --threads).
+int jsg_stft_db_launch_many_threads(const jsg_plan* plan, const jsg_stft_args* args, int count, void* const* streams, int n_streams,
+                                    int n_threads) {
+    if (n_threads <= 1 || n_streams <= 1) return jsg_stft_db_launch_many(plan, args, count, streams, n_streams);
+    if (!plan || (!args && count > 0) || count < 0 || !streams) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch_many_threads: bad argument");
+    if (n_threads > n_streams) n_threads = n_streams;
+    if (n_threads > 16) n_threads = 16;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return jsg_fail(JSG_ERR_NO_DEVICE, "jsg_stft_db_launch_many_threads: no device");
+    std::vector<int> rcs(size_t(n_threads), JSG_OK);
+    std::vector<std::string> errs{size_t(n_threads)};
+    auto body = [&](int t) {
+        if (hipSetDevice(dev) != hipSuccess) { rcs[size_t(t)] = JSG_ERR_HIP; return; }
+        for (int i = 0; i < count; ++i) {
+            if ((i % n_streams) % n_threads != t) continue;
+            const int rc = jsg_stft_db_launch(plan, &args[i], streams[i % n_streams]);
+            if (rc != JSG_OK) { rcs[size_t(t)] = rc; errs[size_t(t)] = tls_error(); return; }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(body, t);
+    body(0);
+    for (auto& x : th) x.join();
+    for (int t = 0; t < n_threads; ++t)
+        if (rcs[size_t(t)] != JSG_OK) { tls_error() = errs[size_t(t)]; return rcs[size_t(t)]; }
     return JSG_OK;
 }
 

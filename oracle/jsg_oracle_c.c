@@ -93,20 +93,45 @@ static void rfft_power(const rfft_plan* p, const float* x, float* power, float* 
     }
 }
 
+/* The plan of the last size used and one set of scratch buffers per thread live across calls (bench.py calls this in
+ * a loop; rebuilding twiddles and malloc'ing per call made the all-cores figure meaningless). */
+static rfft_plan* g_plan = 0;
+static _Thread_local float* t_buf = 0;      /* frame (n) + work (n) + power (h * channels) */
+static _Thread_local size_t t_buf_floats = 0;
+
+static float* thread_buffers(size_t floats) {
+    if (t_buf_floats < floats) {
+        free(t_buf);
+        t_buf = (float*)malloc(sizeof(float) * floats);
+        t_buf_floats = t_buf ? floats : 0;
+    }
+    return t_buf;
+}
+
 /* mix modes: Spectrogram::ChannelMixMode order (0 AbsMean, 1 Max, 2 Min, 3 Left, 4 Right) */
 int jsg_oracle_stft_db(const float* x, int channels, long pitch, int n, int hop, int feedblocks, long n_frames,
                        const float* win, int mix, float power_scale, float* out_db, int threads) {
     const int h = n / 2 + 1;
     if (n < 4 || (n & (n - 1)) || channels < 1) return -1;
-    rfft_plan* plan = plan_create(n);
+    if (!g_plan || g_plan->n != n) {   /* (single caller at a time: tests and bench.py) */
+        if (g_plan) plan_destroy(g_plan);
+        g_plan = plan_create(n);
+    }
+    const rfft_plan* plan = g_plan;
+    int failed = 0;
     (void)threads;
 #pragma omp parallel num_threads(threads > 0 ? threads : 1)
     {
-        float* frame = (float*)malloc(sizeof(float) * n);
-        float* work = (float*)malloc(sizeof(float) * n);
-        float* pw = (float*)malloc(sizeof(float) * (size_t)h * channels);
+        float* frame = thread_buffers((size_t)2 * n + (size_t)h * channels);
+        if (!frame) {
+#pragma omp atomic write
+            failed = 1;
+        }
+        float* work = frame ? frame + n : 0;
+        float* pw = frame ? work + n : 0;
 #pragma omp for schedule(static)
         for (long j = 0; j < n_frames; ++j) {
+            if (!frame) continue;
             const long start = (j / feedblocks) * (long)n + (j % feedblocks) * (long)hop;
             for (int c = 0; c < channels; ++c) {
                 const float* src = x + (long)c * pitch + start;
@@ -129,8 +154,25 @@ int jsg_oracle_stft_db(const float* x, int channels, long pitch, int n, int hop,
                 dst[k] = (float)(10.0 * log10((double)(v + 0.00000000001f)));
             }
         }
-        free(frame); free(work); free(pw);
     }
-    plan_destroy(plan);
+    return failed ? -2 : 0;
+}
+
+/* CColorPalette::getRGBColor over a block of dB columns (CColorpalette.h:34-45) with the pixel placement of a full recolour
+ * in ring order x = column, y = H-1-bin (Spectrogram.cpp:632-648): the CPU side of the C5 end-to-end baseline. */
+int jsg_oracle_colour_columns(const float* db, long n_cols, int h, const int* lut, int n_colors, float vmin, float vmax, float mult,
+                              unsigned* argb, long argb_pitch, int threads) {
+    if (!db || !lut || !argb || h < 1 || n_colors < 1) return -1;
+    (void)threads;
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+    for (long c = 0; c < n_cols; ++c)
+        for (int k = 0; k < h; ++k) {
+            float v = db[(size_t)c * h + k];
+            if (v >= vmax) v = vmax * 0.9999f;
+            if (v < vmin) v = vmin;
+            int idx = (int)((v - vmin) * mult);
+            if (idx >= n_colors) idx = n_colors - 1;
+            argb[(size_t)(h - 1 - k) * argb_pitch + c] = (unsigned)lut[idx] | 0xFF000000u;
+        }
     return 0;
 }

@@ -2,38 +2,61 @@
 """Condense the rocprofv3 output of tools/profile_bench.sh into small, committable summaries (profiles/)."""
 import csv, glob, json, os, sys, collections
 out_dir, tag = sys.argv[1], sys.argv[2]
+cfg = sys.argv[3] if len(sys.argv) > 3 else "c2"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+import bench
 dst = os.path.join(os.environ.get("GRAFT_REPO_ROOT", root), "gpurun_out", f"profiles_{tag}")
 os.makedirs(dst, exist_ok=True)
-res = {"tag": tag, "command": "python3 bench.py --streams 1 --steps 5000 --warmup 500 --no-cpu-baseline"}
+res = {"tag": tag, "config": cfg, "command": open(os.path.join(out_dir, "command.txt")).read().strip().replace(os.environ.get("GRAFT_REPO_ROOT", root) + "/", "")}
+try:
+    res["commit"] = json.load(open(os.path.join(root, "jadespectrogram_amd", "_build_info.json"))).get("commit")
+except Exception:
+    res["commit"] = None
+# the bench line printed under the tracer (its in-order number must agree with the tracer's average)
+try:
+    line = json.loads(open(os.path.join(out_dir, "bench_lines.jsonl")).readline())
+    res["bench_line_under_trace"] = {"value": line["value"], "unit": line["unit"], "avg_launch_us": line["roofline"]["avg_launch_us"],
+                                     "frac_of_8p0": line["roofline"]["frac_of_8p0"]}
+except Exception:
+    pass
 # 1. kernel stats
+main_kernel = "stft_db_kernel"
 for f in glob.glob(os.path.join(out_dir, "stats", "**", "*kernel_stats.csv"), recursive=True):
     rows = list(csv.DictReader(open(f)))
-    with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as fh:
+    with open(os.path.join(dst, f"{tag}_{cfg}_kernel_stats.csv"), "w") as fh:
         w = csv.DictWriter(fh, fieldnames=rows[0].keys()); w.writeheader()
         for r in rows:
             r["Name"] = r["Name"][:120]
             w.writerow(r)
+    res["kernels"] = {}
     for r in rows:
-        if "stft_db_kernel" in r["Name"]:
-            res["kernel"] = r["Name"][:120]
-            res["calls"] = int(r["Calls"]); res["avg_ns"] = float(r["AverageNs"])
-            res["min_ns"] = float(r["MinNs"]); res["max_ns"] = float(r["MaxNs"])
-# 2. counters (per dispatch means over the stft kernel)
-agg = collections.defaultdict(list)
+        for key in ("stft_db_kernel", "colormap_kernel"):
+            if key in r["Name"]:
+                res["kernels"][key] = {"name": r["Name"][:120], "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
+                                       "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3}
+    if main_kernel in res["kernels"]:
+        res["avg_us"] = sum(k["avg_us"] for k in res["kernels"].values())   # c5: both kernels of a launch
+# 2. counters (per dispatch means)
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(out_dir, "*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "stft_db_kernel" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-res["counters_mean_per_dispatch"] = {k: sum(v) / len(v) for k, v in sorted(agg.items())}
-c = res["counters_mean_per_dispatch"]
-if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        for key in ("stft_db_kernel", "colormap_kernel"):
+            if key in r["Kernel_Name"]:
+                agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+res["counters_mean_per_dispatch"] = {k: {c: sum(v) / len(v) for c, v in sorted(d.items())} for k, d in agg.items()}
+fetch = sum(d.get("FETCH_SIZE", 0.0) for d in res["counters_mean_per_dispatch"].values())
+write = sum(d.get("WRITE_SIZE", 0.0) for d in res["counters_mean_per_dispatch"].values())
+if fetch and write:
     # MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of the
     # bytes of a wide coalesced streaming read -> doubled; WRITE_SIZE is exact for streaming stores.
-    res["fetch_bytes_raw"] = c["FETCH_SIZE"] * 1024
-    res["fetch_bytes_corrected"] = c["FETCH_SIZE"] * 1024 * 2
-    res["write_bytes"] = c["WRITE_SIZE"] * 1024
+    res["fetch_bytes_raw"] = fetch * 1024
+    res["fetch_bytes_corrected"] = fetch * 1024 * 2
+    res["write_bytes"] = write * 1024
     res["hbm_bytes_per_launch"] = res["fetch_bytes_corrected"] + res["write_bytes"]
-    res["algorithmic_bytes_per_launch"] = 4100 * 4096
-json.dump(res, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1)
+    res["algorithmic_bytes_per_launch"] = bench.algorithmic_bytes_per_launch(bench.CONFIGS[cfg])
+    res["traffic_over_algorithmic"] = res["hbm_bytes_per_launch"] / res["algorithmic_bytes_per_launch"]
+    if "avg_us" in res:
+        res["frac_of_8p0_from_trace_avg"] = res["algorithmic_bytes_per_launch"] / (res["avg_us"] * 1e-6) / 8e12
+json.dump(res, open(os.path.join(dst, f"{tag}_{cfg}_hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
