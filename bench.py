@@ -211,6 +211,8 @@ def main():
     ap.add_argument("--issue-threads", type=int, default=2, help="host threads issuing the launches of a step (c2, streams > 1)")
     ap.add_argument("--blocks-per-cu", type=int, default=1, help="workgroups per CU of each launch when launches overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="issue the in-order launches from the host instead of replaying a hipGraph "
+                                                            "(rocprofv3 does not see kernels inside graph replays, and its counter passes crash on them)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work at all: exercises the N-rank plumbing (barriers, reductions, "
                                                            "JSON) on a machine without GPUs; value is null")
     args = ap.parse_args()
@@ -304,19 +306,35 @@ def main():
                             stream=stream_handle)
 
         # ---- the in-order group of one step as a hipGraph on ONE stream (per-kernel view; the timed region of c3 / c5) ----
-        graph = torch.cuda.CUDAGraph()
         with torch.cuda.stream(one):
             for b in range(min(nbuf, lps)):
                 launch(b, one.cuda_stream)
             torch.cuda.synchronize()
-            with torch.cuda.graph(graph, stream=one):
+        if args.no_graph:
+            if c["colour"]:
+                def replay_inorder():
+                    for i in range(lps):
+                        launch(i % nbuf, one.cuda_stream)
+            else:
+                arr1 = (capi.StftArgs * lps)()
                 for i in range(lps):
-                    launch(i % nbuf, one.cuda_stream)
-        torch.cuda.synchronize()
+                    a_i = _stft_args(plan, d_in[i % nbuf], hop, F, d_out[i % nbuf], feedblocks=fb, mix_mode=jsg.capi.MIX_ABSMEAN)
+                    ctypes.memmove(ctypes.byref(arr1, i * ctypes.sizeof(capi.StftArgs)), ctypes.byref(a_i), ctypes.sizeof(capi.StftArgs))
+                one_arr = (ctypes.c_void_p * 1)(one.cuda_stream)
 
-        def replay_inorder():
+                def replay_inorder():
+                    capi.check(lib.jsg_stft_db_launch_many(plan._p, arr1, lps, one_arr, 1))
+        else:
+            graph = torch.cuda.CUDAGraph()
             with torch.cuda.stream(one):
-                graph.replay()
+                with torch.cuda.graph(graph, stream=one):
+                    for i in range(lps):
+                        launch(i % nbuf, one.cuda_stream)
+            torch.cuda.synchronize()
+
+            def replay_inorder():
+                with torch.cuda.stream(one):
+                    graph.replay()
 
         if n_streams > 1:
             # ---- the overlapped group: lps independent launches from ONE C call over n_streams streams ----
@@ -363,11 +381,11 @@ def main():
         with torch.cuda.stream(one):
             ev0.record(one)
             for _ in range(reps):
-                graph.replay()
+                replay_inorder()
             ev1.record(one)
         torch.cuda.synchronize()
         inorder_us = ev0.elapsed_time(ev1) * 1e3 / (reps * lps)
-        if not c["colour"]:   # host-issued launches on the same stream, for comparison (adds the runtime's per-launch handling)
+        if not c["colour"] and not args.no_graph:   # host-issued launches on the same stream, for comparison (adds the runtime's per-launch handling)
             k = min(lps, 512)
             with torch.cuda.stream(one):
                 for i in range(64):
@@ -385,7 +403,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, inorder_us = float(t[0]), (float(t[1]) or None)
 
-    if rank == 0 and not args.dry_run:
+    if rank == 0 and not args.dry_run and not args.no_graph:
         # context for the roofline: a plain device-to-device copy of the SAME byte count, same rotation, same graph timing --
         # what a launch of this size can reach at all on this GPU
         nflt = algo // 8
@@ -406,8 +424,8 @@ def main():
         torch.cuda.synchronize()
         copy_us = c0.elapsed_time(c1) * 1e3 / (4 * min(lps, 256))
         del csrc, cdst, g2
-        if world == 1:
-            parity = parity_report(jsg, c, plan, base, win)
+    if rank == 0 and not args.dry_run and world == 1:
+        parity = parity_report(jsg, c, plan, base, win)
 
     units_total = world * args.steps * lps * units_per_launch
     out = {
@@ -418,7 +436,7 @@ def main():
                    "step": f"{lps} launches x {F} {'columns' if c['colour'] or C > 1 else 'frames'} = {lps * units_per_launch} {c['unit'].split('/')[0]} per step and GPU",
                    "launches_per_step": lps, "frames_per_launch": F * C, "columns_per_launch": F, "channels_per_gpu": C,
                    "distinct_batches": nbuf, "hip_streams_per_gpu": n_streams,
-                   "issue": ("hipGraph replay, in order" if n_streams == 1 else f"one C call per step, {max(1, args.issue_threads)} host thread(s)"),
+                   "issue": (("host-issued, in order on one stream" if args.no_graph else "hipGraph replay, in order") if n_streams == 1 else f"one C call per step, {max(1, args.issue_threads)} host thread(s)"),
                    "prewarm_s": round(prewarm_s, 3),
                    "parallelism": f"{world} GPU(s), independent batches, no data-path collective"},
     }
@@ -444,7 +462,7 @@ def main():
             "kernel": ("stft_db_kernel<4096, AbsMean, index out> + colormap_kernel (jsg_stft_image_launch)" if c["colour"]
                        else f"stft_db_kernel<{n}>"),
             "avg_launch_us": inorder_us, "avg_launch_us_host_issued": eager_us,
-            "how": f"HIP events on the launch stream around hipGraph replays of the step's {lps} launches, one at a time in order",
+            "how": f"HIP events on the launch stream around {'host-issued runs' if args.no_graph else 'hipGraph replays'} of the step's {lps} launches, one at a time in order",
             "algorithmic_bytes_per_launch": algo,
             "timed_region_achieved": conc, "timed_region_frac_of_8p0": conc / HBM_PEAK_GBS, "timed_region_frac_of_6p3": conc / HBM_ACHIEVABLE_GBS,
             "note": "achieved/frac: per-kernel view (in order, one stream); timed_region_*: algorithmic bytes of the K timed steps / their wall "

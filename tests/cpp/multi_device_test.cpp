@@ -1,0 +1,94 @@
+// Several GPUs from ONE host process through the C-ABI ("Several GPUs"): one jsg_engine per device,
+// channels sharded contiguously, every engine fed from its own host thread, outputs stay on their device -- the path
+// shards by independent channels, so there is no collective.  On a box with one GPU the shards share it.
+//   usage: multi_device_test [n_shards]      (default: one shard per visible device, at least 2)
+// Check: every channel's spectrogram from the sharded run equals the same channel of ONE engine that holds all channels
+// (per-channel mode), bit for bit.  Prints one JSON line.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../include/jsg.h"
+
+#define CK(call)                                                                         \
+    do {                                                                                 \
+        int rc_ = (call);                                                                \
+        if (rc_ < 0) {                                                                   \
+            std::fprintf(stderr, "%s -> %d: %s\n", #call, rc_, jsg_last_error(nullptr)); \
+            std::exit(2);                                                                \
+        }                                                                                \
+    } while (0)
+
+static void configure(jsg_engine* e) {
+    CK(jsg_set_samplerate(e, 48000.f));
+    CK(jsg_set_memory_time_s(e, 1.f));
+    CK(jsg_set_fft_size(e, 1024));
+    CK(jsg_set_feed_percent(e, JSG_FEED_50));
+    CK(jsg_set_mix_mode(e, JSG_MIX_PER_CHANNEL));
+}
+
+int main(int argc, char** argv) {
+    const int ndev = jsg_device_count();
+    if (ndev <= 0) { std::fprintf(stderr, "no device\n"); return 2; }
+    const int shards = argc > 1 ? std::atoi(argv[1]) : std::max(2, ndev);
+    const int C = 8, N = 1024, blocks = 12;
+    std::vector<float> x(size_t(C) * blocks * N);
+    for (int c = 0; c < C; ++c)
+        for (int i = 0; i < blocks * N; ++i)
+            x[size_t(c) * blocks * N + i] = 0.5f * std::sin(0.002f * float(c + 3) * float(i)) + 0.001f * float((i * 7919 + c * 104729) % 1000 - 500);
+
+    // reference: one engine with all 8 channels
+    jsg_engine* whole = nullptr;
+    CK(jsg_create_on_device(&whole, C, 0));
+    configure(whole);
+    CK(jsg_process_blocks(whole, x.data(), int64_t(blocks) * N, blocks));
+    const int W = jsg_get_memory_size(whole), H = jsg_get_spectrum_size(whole);
+    std::vector<float> ref(size_t(C) * W * H);
+    int pos_ref = 0;
+    CK(jsg_peek_mem(whole, ref.data(), C * W, &pos_ref));
+
+    // sharded: engine s owns channels [first[s], first[s] + count[s]) on device s % ndev
+    std::vector<jsg_engine*> eng(size_t(shards), static_cast<jsg_engine*>(nullptr));
+    const size_t ns = size_t(shards);
+    std::vector<int> first(ns, 0), count(ns, 0);
+    for (int s = 0; s < shards; ++s) {
+        const int base = C / shards, extra = C % shards;
+        first[size_t(s)] = s * base + std::min(s, extra);
+        count[size_t(s)] = base + (s < extra ? 1 : 0);
+        if (count[size_t(s)] == 0) continue;
+        CK(jsg_create_on_device(&eng[size_t(s)], count[size_t(s)], s % ndev));
+        if (jsg_get_device(eng[size_t(s)]) != s % ndev) return 3;
+        configure(eng[size_t(s)]);
+    }
+    std::vector<std::thread> feeders;   // one host thread per engine: block by block, like audio callbacks
+    for (int s = 0; s < shards; ++s) {
+        if (!eng[size_t(s)]) continue;
+        feeders.emplace_back([&, s] {
+            std::vector<const float*> ptrs(size_t(count[size_t(s)]));
+            for (int b = 0; b < blocks; ++b) {
+                for (int c = 0; c < count[size_t(s)]; ++c) ptrs[size_t(c)] = x.data() + size_t(first[size_t(s)] + c) * blocks * N + size_t(b) * N;
+                CK(jsg_process_block(eng[size_t(s)], ptrs.data()));
+            }
+        });
+    }
+    for (auto& t : feeders) t.join();
+    size_t diff = 0;
+    int pos_bad = 0;
+    for (int s = 0; s < shards; ++s) {
+        if (!eng[size_t(s)]) continue;
+        std::vector<float> got(size_t(count[size_t(s)]) * W * H);
+        int pos = -1;
+        CK(jsg_peek_mem(eng[size_t(s)], got.data(), count[size_t(s)] * W, &pos));
+        pos_bad += pos != pos_ref;
+        diff += std::memcmp(got.data(), ref.data() + size_t(first[size_t(s)]) * W * H, got.size() * sizeof(float)) != 0;
+        CK(jsg_destroy(eng[size_t(s)]));
+    }
+    CK(jsg_destroy(whole));
+    std::printf("{\"devices\": %d, \"shards\": %d, \"channels\": %d, \"columns\": %d, \"shards_differing\": %zu, \"pos_mismatch\": %d}\n", ndev,
+                shards, C, 2 * blocks, diff, pos_bad);
+    return diff == 0 && pos_bad == 0 ? 0 : 1;
+}

@@ -10,13 +10,19 @@ TAG=${1:-r02}; CFG=${2:-c2}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_bench_${TAG}_${CFG}
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# --streams 1: the timed region itself is the in-order hipGraph replay (one launch at a time), so rocprofv3's per-dispatch
-# duration is the per-kernel number that bench.py's `roofline` reports; the driver-shaped step counts are used as they are
-CMD="python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --streams 1 --steps 20 --warmup 5 --no-cpu-baseline"
+# --streams 1 --no-graph: the timed region is one launch at a time, host-issued (rocprofv3 neither traces nor counts kernels
+# inside hipGraph replays -- its counter passes crash on them), so the per-dispatch duration is the per-kernel number
+# that bench.py's `roofline` reports; the driver-shaped step counts are used as they are
+CMD="python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --streams 1 --no-graph --steps 20 --warmup 5 --no-cpu-baseline"
+# counter passes: the same launches, fewer of them (the collector serialises every dispatch, and crashed on the 25 000
+# queued dispatches of the full-size command); counters are per-dispatch means, so the count does not matter
+PMC_CMD="$CMD --launches-per-step 32 --steps 10 --warmup 2"
 echo "$CMD" > $OUT/command.txt
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1 || echo "stats pass failed"
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/fetch.log 2>&1 || echo "fetch pass failed"
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/write.log 2>&1 || echo "write pass failed"
-timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY --output-format csv -d $OUT/sq -- $CMD > $OUT/sq.log 2>&1 || echo "sq pass failed"
-grep -h '"metric"' $OUT/*.log | head -4 > $OUT/bench_lines.jsonl
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $PMC_CMD > $OUT/fetch.log 2>&1 || echo "fetch pass failed"
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $PMC_CMD > $OUT/write.log 2>&1 || echo "write pass failed"
+timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY --output-format csv -d $OUT/sq -- $PMC_CMD > $OUT/sq.log 2>&1 || echo "sq pass failed"
+grep -h '"metric"' $OUT/stats.log | head -1 > $OUT/bench_lines.jsonl
 python3 $GRAFT_REPO_ROOT/tools/profile_summarize.py $OUT $TAG $CFG
+# the raw per-dispatch files are large (tens of MB per configuration; gpurun copies back at most 64 MiB): keep the summaries
+find $OUT -name '*kernel_trace.csv' -delete; find $OUT -name '*counter_collection.csv' -delete
