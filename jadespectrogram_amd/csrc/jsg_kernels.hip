@@ -189,7 +189,19 @@ struct Cfg {
     // only through n2 = t1 / R3, stored once per n2 as [R2][TS1] (row stride R1 + 1: the R3 lanes of a group read one
     // address, the groups of a wave fall into different banks); stage-2 twiddles [P][TL]; post-pass twiddles of the
     // lower half of the bins [P/2][TL]
+#ifdef JSG_X_TAB8
+    static constexpr bool TABPAIR = false;           // (A/B) every table value is read with its own 8-byte LDS load
     static constexpr int TS1 = R1_ + 1;
+#else
+    // The lane tables are read two values (16 bytes) at a time: ds_read_b128 moves 1 KiB per wave-instruction at the full
+    // LDS rate even with one or two waves per SIMD, 8-byte reads need about four (MI355X_MICROARCH.md, LDS), and every
+    // table value is used by exactly one instruction -- so value j of a lane sits next to value j+1: element (j, e) of
+    // a [J][TL] table is stored at ((j / 2) * TL + e) * 2 + j % 2.  Stage-1 rows hold k1 = 1.. at column k1 - 1, row stride
+    // R1 + 2 (16-byte aligned rows whose 16-byte chunks fall into different banks for the n2 groups of a wave).
+    static constexpr bool TABPAIR = true;
+    static constexpr int TS1 = R1_ + 2;
+#endif
+    static constexpr int tab_idx(int j, int e) { return TABPAIR ? ((j / 2) * (L_ > 64 ? L_ : 64) + e) * 2 + j % 2 : j * (L_ > 64 ? L_ : 64) + e; }
     static constexpr int TAB_WIN = 0, TAB_TW1 = P * TL, TAB_TW2 = TAB_TW1 + R2_ * TS1, TAB_POST = TAB_TW2 + P * TL;
     static constexpr int TAB_ELEMS = TAB_POST + (P / 2) * TL;
     static constexpr int e1max = (R1 - 1) * S1 + M / R1;
@@ -478,24 +490,24 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     } else {
         tWin = reinterpret_cast<const cf*>(a.tab) + tl;
     }
-    const cf* const tTw1 = tWin - tl + C::TAB_TW1;   // compact: [n2][TS1], not indexed by lane
-    const cf* const tTw2 = tWin + C::TAB_TW2;
-    const cf* const tPost = tWin + C::TAB_POST;
+    const cf* const tBase = tWin - tl;               // start of the tables (LDS copy, or global memory for TLOC == 0)
+    const cf* const tTw1 = tBase + C::TAB_TW1;       // compact: [n2][TS1], not indexed by lane
     int tw1row[U1];                                   // row of this lane's butterfly u in the stage-1 table
 #pragma unroll
     for (int u = 0; u < U1; ++u) tw1row[u] = ((ll + L * u) / R3) * C::TS1;
-    constexpr int NR = C::TLOC == 2 ? P : 1;
-    cf rWin[NR], rTw1[NR], rTw2[NR], rPost[NR];
-    if constexpr (C::TLOC == 2) {
-#pragma unroll
-        for (int j = 0; j < P; ++j) {
-            rWin[j] = tWin[j * TL];
-            rTw1[j] = tTw1[tw1row[j / R1] + j % R1];
-            rTw2[j] = tTw2[j * TL];
-            if (j < P / 2) rPost[j] = tPost[j * TL];
+    static_assert(C::TLOC != 2, "lane tables in registers: removed (DESIGN.md, tried and measured)");
+    // value j of this lane from the [J][TL] table at `off`; with the pair layout an even j fetches j and j + 1 at once
+    auto tab1 = [&](int off, int j) -> cf { return tBase[off + C::tab_idx(j, tl)]; };
+    auto tab2 = [&](int off, int j, cf& a0, cf& a1) {
+        if constexpr (C::TABPAIR) {
+            const v4f q = *reinterpret_cast<const v4f*>(tBase + off + C::tab_idx(j, tl));
+            a0 = cf{q.x, q.y};
+            a1 = cf{q.z, q.w};
+        } else {
+            a0 = tab1(off, j);
+            a1 = tab1(off, j + 1);
         }
-    }
-#define JSG_T(reg, ptr, j) (C::TLOC == 2 ? reg[C::TLOC == 2 ? (j) : 0] : ptr[(j) * TL])
+    };
     // exchange synchronisation: lock-step lanes of one wave need only a compiler fence; frames that span several
     // waves (L > 64) need the workgroup barrier (every wave of the workgroup runs the same number of them)
     auto frame_sync = [&]() {
@@ -542,9 +554,12 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
             for (int m = 0; m < P; ++m) raw[m] = src[L * m];
         }
 #pragma unroll
-        for (int m = 0; m < P; ++m) {
-            const cf w = (C::ABLX == 11 || C::ABLX == 14) ? cf{0.5f, 0.25f} : JSG_T(rWin, tWin, m);
-            x[m] = to_cf(raw[m]) * w;
+        for (int m = 0; m < P; m += 2) {
+            cf w0, w1;
+            if constexpr (C::ABLX == 11 || C::ABLX == 14) w0 = w1 = cf{0.5f, 0.25f};
+            else tab2(C::TAB_WIN, m, w0, w1);
+            x[m] = to_cf(raw[m]) * w0;
+            x[m + 1] = to_cf(raw[m + 1]) * w1;
         }
         if constexpr (C::ABL == 3) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -572,9 +587,17 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
             for (int n1 = 0; n1 < R1; ++n1) t[n1] = x[u + U1 * n1];
             dft<R1>(t);
             lds[ll + L * u] = t[0];
+            if constexpr (C::TABPAIR) {   // row: k1 = 1, 2 | 3, 4 | ... | R1 - 1, (pad)
 #pragma unroll
-            for (int k1 = 1; k1 < R1; ++k1)
-                lds[k1 * C::S1 + ll + L * u] = cmul(t[k1], C::TLOC == 2 ? rTw1[C::TLOC == 2 ? u * R1 + k1 : 0] : tTw1[tw1row[u] + k1]);
+                for (int k1 = 1; k1 < R1; k1 += 2) {
+                    const v4f q = *reinterpret_cast<const v4f*>(tTw1 + tw1row[u] + k1 - 1);
+                    lds[k1 * C::S1 + ll + L * u] = cmul(t[k1], cf{q.x, q.y});
+                    if (k1 + 1 < R1) lds[(k1 + 1) * C::S1 + ll + L * u] = cmul(t[k1 + 1], cf{q.z, q.w});
+                }
+            } else {
+#pragma unroll
+                for (int k1 = 1; k1 < R1; ++k1) lds[k1 * C::S1 + ll + L * u] = cmul(t[k1], tTw1[tw1row[u] + k1]);
+            }
         }
         frame_sync();
 #pragma unroll
@@ -591,7 +614,12 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
             for (int n2 = 0; n2 < R2; ++n2) t[n2] = x[v * R2 + n2];
             dft<R2>(t);
 #pragma unroll
-            for (int k2 = 0; k2 < R2; ++k2) lds[e2w[v] + k2 * C::AY] = cmul(t[k2], JSG_T(rTw2, tTw2, v * R2 + k2));
+            for (int k2 = 0; k2 < R2; k2 += 2) {
+                cf w0, w1;
+                tab2(C::TAB_TW2, v * R2 + k2, w0, w1);
+                lds[e2w[v] + k2 * C::AY] = cmul(t[k2], w0);
+                lds[e2w[v] + (k2 + 1) * C::AY] = cmul(t[k2 + 1], w1);
+            }
         }
         frame_sync();
         // ---- stage 3: radix-R3 over n3; Z[k], k = t3 + R1 R2 k3 ----
@@ -626,11 +654,14 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
 #pragma unroll
             for (int rho = 0; rho < P / 2; ++rho) zq[rho] = lds[M - (ll + L * rho)];
             frame_sync();   // the next FFT's exchange stores must stay behind these loads
+            cf wpost[P / 2];
+#pragma unroll
+            for (int rho = 0; rho < P / 2; rho += 2) tab2(C::TAB_POST, rho, wpost[rho], wpost[rho + 1]);
 #pragma unroll
             for (int rho = 0; rho < P / 2; ++rho) {
                 const cf z = x[reg_of(rho)], p = zq[rho];
                 const cf S = add_conj(z, p);
-                const cf T = cmul(sub_conj(z, p), JSG_T(rPost, tPost, rho));
+                const cf T = cmul(sub_conj(z, p), wpost[rho]);
                 const cf xa = S + T, xb = S - T;
                 acc[rho] = mix_combine<MIXOP>(acc[rho], xa.x * xa.x + xa.y * xa.y);
                 acc[P / 2 + rho] = mix_combine<MIXOP>(acc[P / 2 + rho], xb.x * xb.x + xb.y * xb.y);
@@ -755,7 +786,6 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
             d[6] = stA; d[7] = stB; d[8] = stC; d[9] = stP;
         }
     }
-#undef JSG_T
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -862,24 +892,25 @@ static void fill_tables(std::vector<float2>& t, const float* window, double amp)
     for (int n2 = 0; n2 < R2; ++n2)   // stage-1 twiddles, one row per n2 (shared by the lanes with t1 / R3 == n2)
         for (int k1 = 0; k1 < R1; ++k1) {
             const double ang = -two_pi * double((long long)n2 * k1 % (R1 * R2)) / double(R1 * R2);
-            t[C::TAB_TW1 + n2 * C::TS1 + k1] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
+            if (C::TABPAIR && k1 == 0) continue;   // the twiddle of k1 = 0 is 1 and never read
+            t[C::TAB_TW1 + n2 * C::TS1 + (C::TABPAIR ? k1 - 1 : k1)] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
         }
     for (int e = 0; e < TL; ++e) {   // entry e of a table row belongs to lane-in-frame ll (L = 32: both half-waves)
         const int ll = e % L;
         for (int m = 0; m < P; ++m) {   // window pairs: samples 2n, 2n+1 with n = ll + L m
             const int n = ll + L * m;
             const double a2 = 0.5 * amp;   // the paired post pass expects Z/2
-            t[C::TAB_WIN + m * TL + e] = make_float2(float(double(window[2 * n]) * a2), float(double(window[2 * n + 1]) * a2));
+            t[C::TAB_WIN + C::tab_idx(m, e)] = make_float2(float(double(window[2 * n]) * a2), float(double(window[2 * n + 1]) * a2));
         }
         for (int v = 0; v < C::U2; ++v)
             for (int k2 = 0; k2 < R2; ++k2) {
                 const int t2 = ll + L * v, k1 = t2 / R3, n3 = t2 % R3;
                 const double ang = -two_pi * double((long long)n3 * (k1 + R1 * k2) % M) / double(M);
-                t[C::TAB_TW2 + (v * R2 + k2) * TL + e] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
+                t[C::TAB_TW2 + C::tab_idx(v * R2 + k2, e)] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
             }
         for (int rho = 0; rho < P / 2; ++rho) {   // bins k = ll + L rho of the lower half: -i exp(i ang) = sin(ang) - i cos(ang)
             const double ang = -two_pi * double(ll + L * rho) / double(N);
-            t[C::TAB_POST + rho * TL + e] = make_float2(float(std::sin(ang)), float(-std::cos(ang)));
+            t[C::TAB_POST + C::tab_idx(rho, e)] = make_float2(float(std::sin(ang)), float(-std::cos(ang)));
         }
     }
 }
