@@ -821,18 +821,27 @@ __global__ __launch_bounds__(256) void colormap_kernel(const CmapKArgs a) {
     // before the first use (one HBM round trip per tile instead of sixteen).
     const int bin = bin0 + lane;
     if (a.idx_in) {   // the STFT kernel has already quantised the column (wave-uniform branch)
-        unsigned char b[CM_TILE / 4];
+        // one 16-byte load per thread: thread t takes bins 16 (t % 4) .. + 15 of column t / 4 of the tile
+        const int tc = tid >> 2, tb = (tid & 3) * 16;
+        const int i = col0 + tc;
+        int col = a.col_first + i;
+        if (col >= a.ring_w) col -= a.ring_w;
+        const unsigned char* src = a.idx_in + (long long)col * a.idx_in_pitch + bin0 + tb;
+        typedef unsigned cu4 __attribute__((ext_vector_type(4)));
+        cu4 w = {0u, 0u, 0u, 0u};
+        const bool whole = i < a.n_cols && bin0 + tb + 16 <= a.height && ((a.idx_in_pitch | reinterpret_cast<unsigned long long>(a.idx_in)) & 15) == 0;
+        if (whole) w = *reinterpret_cast<const cu4*>(src);
+        else if (i < a.n_cols) {   // ragged edge of the image, or an unaligned scratch: byte by byte
+            unsigned char bb[16];
 #pragma unroll
-        for (int q = 0; q < CM_TILE / 4; ++q) {
-            const int i = col0 + wave + 4 * q;
-            int col = a.col_first + i;
-            if (col >= a.ring_w) col -= a.ring_w;
-            b[q] = (i < a.n_cols && bin < a.height) ? a.idx_in[(long long)col * a.idx_in_pitch + bin] : (unsigned char)0;
+            for (int k = 0; k < 16; ++k) bb[k] = bin0 + tb + k < a.height ? src[k] : (unsigned char)0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = bb[4 * k] | bb[4 * k + 1] << 8 | bb[4 * k + 2] << 16 | (unsigned)bb[4 * k + 3] << 24;
         }
         if (lut_in_lds)
-            for (int i = tid; i < a.n_colors; i += 256) s_lut[i] = a.lut[i];
+            for (int k = tid; k < a.n_colors; k += 256) s_lut[k] = a.lut[k];
 #pragma unroll
-        for (int q = 0; q < CM_TILE / 4; ++q) s_idx[lane][wave + 4 * q] = b[q];
+        for (int k = 0; k < 16; ++k) s_idx[tb + k][tc] = (unsigned short)((w[k >> 2] >> (8 * (k & 3))) & 0xffu);
     } else {
         float v[CM_TILE / 4];
 #pragma unroll
