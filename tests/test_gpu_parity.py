@@ -314,7 +314,7 @@ def test_producer_and_consumer_threads(jsg, oracle):
 
 
 def test_integration_md_ctypes_snippet(jsg):
-    """The raw-ctypes example of INTEGRATION.md section C, verbatim in spirit: plain C-ABI, no package helpers."""
+    """The raw-ctypes example of INTEGRATION.md section D, verbatim in spirit: plain C-ABI, no package helpers."""
     import ctypes as C
     lib = C.CDLL(jsg.capi.LIB_PATH)
     h = C.c_void_p()
