@@ -100,6 +100,20 @@ static const Config kConfigs[] = {
     {"c5", 4096, 512, 2, 1875, JSG_MIX_ABSMEAN, true},     // configs[4]: stereo, 87.5 % overlap, 10 s ring -> ARGB
     {"big", 1024, 512, 1, 65536, JSG_MIX_ABSMEAN, false},  // asymptotic rate of the 1024-point plan
     {"c3big", 2048, 512, 8, 16384, JSG_MIX_ABSMEAN, false},
+    // --cfg sizes: every plan at 50 % and 75 % overlap, mono, launches of 64 Mi samples' worth of frames
+    {"sizes", 512, 256, 1, 131072, JSG_MIX_ABSMEAN, false},
+    {"sizes", 512, 128, 1, 131072, JSG_MIX_ABSMEAN, false},
+    {"sizes", 1024, 512, 1, 65536, JSG_MIX_ABSMEAN, false},
+    {"sizes", 1024, 256, 1, 65536, JSG_MIX_ABSMEAN, false},
+    {"sizes", 2048, 1024, 1, 32768, JSG_MIX_ABSMEAN, false},
+    {"sizes", 2048, 512, 1, 32768, JSG_MIX_ABSMEAN, false},
+    {"sizes", 4096, 2048, 1, 16384, JSG_MIX_ABSMEAN, false},
+    {"sizes", 4096, 1024, 1, 16384, JSG_MIX_ABSMEAN, false},
+    {"sizes", 8192, 4096, 1, 8192, JSG_MIX_ABSMEAN, false},
+    {"sizes", 8192, 2048, 1, 8192, JSG_MIX_ABSMEAN, false},
+    // --cfg c4sweep: the C4 shard (8 channels per GPU, per-channel columns) at other launch sizes
+    {"c4sweep", 1024, 512, 8, 1024, JSG_MIX_PER_CHANNEL, false},
+    {"c4sweep", 1024, 512, 8, 16384, JSG_MIX_PER_CHANNEL, false},
 };
 
 // GPU-side time per launch with the host taken out: `issue(count)` enqueues `count` launches on `st`; they are captured
