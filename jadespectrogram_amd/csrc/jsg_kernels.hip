@@ -35,8 +35,6 @@
 
 namespace jsg {
 
-#define GETREG_HW_ID ((32 - 1) << 11 | 4)   // s_getreg_b32 hwreg(HW_REG_HW_ID, 0, 32): wave / SIMD / CU / SE / XCC of this wave
-
 // ------------------------------------------------------------------------------------------------------------
 // complex arithmetic on packed pairs: cf = (re, im) in one aligned 64-bit VGPR pair.
 //
@@ -164,44 +162,41 @@ __device__ __forceinline__ cf to_cf(const f2u& v) { return cf{v.x, v.y}; }
 // per-size configuration (mirrors tools/fft_model.py CONFIGS; layouts found by its conflict search)
 // ------------------------------------------------------------------------------------------------------------
 // TLOC: where the lane tables (window pairs, stage-1/2 twiddles, post-pass twiddles; layout: Cfg::TAB_*) live:
-//   0 = read from global memory (L1/L2) at every use, 1 = staged once per workgroup into LDS and read from there,
-//   2 = loaded once per wave into registers.
+//   0 = read from global memory (L1/L2) at every use, 1 = brought into LDS once per workgroup and read from there.
+// FPW:  frames a wavefront transforms at the same time, as one interleaved instruction stream (L = 64 plans; every stage of
+//   the kernel loops over the frames inside one basic block).  The idea: two independent dependency chains fill each
+//   other's LDS round trips, tables and address arithmetic are paid once per pair.  Measured with FPW = 2 (4-wave
+//   workgroups, 100 VGPRs): bit-identical results, but C2 5.89 instead of 5.20 us per launch and -4 % on 65 536-frame
+//   launches -- four independent wavefronts per SIMD hide latency better than two twice-as-long ones, and a wave has to
+//   wait for both frames' data.  All plans use 1 (tried and measured).
+// ABL:  development ablations (builds with -DJSG_X_ABL=n): 1 = memory traffic only, 2 = compute only, 3 = in-kernel
+//   stamps, 5 = return at once (launch cost of the kernel's resource footprint).
 template <int N_, int R1_, int R2_, int R3_, int L_, int S1_, int AX_, int AY_, int AZ_, int WPB_, int TLOC_, int WPS_,
-          int PF_ = 1, int ABL_ = 0, bool NT_ = true>
+          int FPW_ = 1, int ABL_ = 0>
 struct Cfg {
-    static constexpr bool NT = NT_;                  // non-temporal (streaming) stores of the dB columns
-    static constexpr int ABLX = ABL_;                // development ablations: 1 = memory traffic only, 2 = compute only, 3 = stamps,
-                                                     // 11..14 = memory-only sub-modes (no table staging / half loads / 16-B stores / all)
-    static constexpr int ABL = ABL_ >= 11 ? 1 : ABL_;
-    static constexpr int PF = PF_;                   // software-prefetch depth in FFTs (1 or 2)
+    static constexpr int ABL = ABL_;
     static constexpr int N = N_, M = N_ / 2, R1 = R1_, R2 = R2_, R3 = R3_, L = L_;
     static constexpr int P = M / L;                  // complex values per lane
     static constexpr int U1 = P / R1, U2 = P / R2, U3 = P / R3;
     static constexpr int S1 = S1_, AX = AX_, AY = AY_, AZ = AZ_;
-    static constexpr int SUB = L < 64 ? 64 / L : 1;  // frames per wavefront (L = 32: two)
+    static constexpr int SUB = L < 64 ? 64 / L : 1;  // frames side by side in one wavefront (L = 32: two)
     static constexpr int WPF = L > 64 ? L / 64 : 1;  // wavefronts per frame (L = 128, 256: the exchanges use s_barrier)
+    static constexpr int FPW = FPW_;                 // frames interleaved in one wavefront's instruction stream
     static constexpr int TL = L > 64 ? L : 64;       // entries per lane-table row
     static constexpr int WPB = WPB_;                 // wavefronts per workgroup
-    static constexpr int TPB = WPB * 64 / L;         // frames per workgroup per iteration
+    static constexpr int TPB = WPB * 64 / L * FPW;   // frames per workgroup per iteration
     static constexpr int TLOC = TLOC_;
     static constexpr int WPS = WPS_;                 // waves per SIMD the register allocator is asked to allow
-    // lane tables (float2 elements): window pairs [P][TL]; stage-1 twiddles W_{R1 R2}^{n2 k1}, which depend on the lane
-    // only through n2 = t1 / R3, stored once per n2 as [R2][TS1] (row stride R1 + 1: the R3 lanes of a group read one
-    // address, the groups of a wave fall into different banks); stage-2 twiddles [P][TL]; post-pass twiddles of the
-    // lower half of the bins [P/2][TL]
-#ifdef JSG_X_TAB8
-    static constexpr bool TABPAIR = false;           // (A/B) every table value is read with its own 8-byte LDS load
-    static constexpr int TS1 = R1_ + 1;
-#else
-    // The lane tables are read two values (16 bytes) at a time: ds_read_b128 moves 1 KiB per wave-instruction at the full
-    // LDS rate even with one or two waves per SIMD, 8-byte reads need about four (MI355X_MICROARCH.md, LDS), and every
-    // table value is used by exactly one instruction -- so value j of a lane sits next to value j+1: element (j, e) of
-    // a [J][TL] table is stored at ((j / 2) * TL + e) * 2 + j % 2.  Stage-1 rows hold k1 = 1.. at column k1 - 1, row stride
+    // Lane tables (float2 elements): window pairs [P][TL]; stage-1 twiddles W_{R1 R2}^{n2 k1}, which depend on the lane
+    // only through n2 = t1 / R3, stored once per n2 as [R2][TS1]; stage-2 twiddles [P][TL]; post-pass twiddles of the
+    // lower half of the bins [P/2][TL].
+    // They are read two values (16 bytes) at a time: ds_read_b128 moves 1 KiB per wave-instruction at the full LDS rate
+    // even with one or two waves per SIMD, 8-byte reads need about four (MI355X_MICROARCH.md, LDS), and every table
+    // value is used by exactly one instruction -- so value j of a lane sits next to value j+1: element (j, e) of a
+    // [J][TL] table is stored at ((j / 2) * TL + e) * 2 + j % 2.  Stage-1 rows hold k1 = 1.. at column k1 - 1, row stride
     // R1 + 2 (16-byte aligned rows whose 16-byte chunks fall into different banks for the n2 groups of a wave).
-    static constexpr bool TABPAIR = true;
     static constexpr int TS1 = R1_ + 2;
-#endif
-    static constexpr int tab_idx(int j, int e) { return TABPAIR ? ((j / 2) * (L_ > 64 ? L_ : 64) + e) * 2 + j % 2 : j * (L_ > 64 ? L_ : 64) + e; }
+    static constexpr int tab_idx(int j, int e) { return ((j / 2) * (L_ > 64 ? L_ : 64) + e) * 2 + j % 2; }
     static constexpr int TAB_WIN = 0, TAB_TW1 = P * TL, TAB_TW2 = TAB_TW1 + R2_ * TS1, TAB_POST = TAB_TW2 + P * TL;
     static constexpr int TAB_ELEMS = TAB_POST + (P / 2) * TL;
     static constexpr int e1max = (R1 - 1) * S1 + M / R1;
@@ -213,39 +208,22 @@ struct Cfg {
     static_assert(R1 * R2 * R3 == M, "radices");
     static_assert(P % R1 == 0 && P % R2 == 0 && P % R3 == 0, "each lane owns whole butterflies");
     static_assert(WPB % WPF == 0, "a workgroup holds whole frames");
+    static_assert(FPW == 1 || L == 64, "interleaved frames: one-wavefront-per-frame plans only");
+    static_assert(TLOC == 0 || TLOC == 1, "lane tables in registers: removed (DESIGN.md, tried and measured)");
     static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget of one CU");
 };
 
-using Cfg512 = Cfg<512, 8, 8, 4, 32, 36, 4, 33, 1, 8, 1, 2>;   // (a 80-VGPR budget = 3 workgroups per CU measured no faster)
-// default 1024-point plan: both exchanges through LDS, prefetch depth 1, 8 waves per workgroup (fastest of the
-// measured variants, DESIGN.md "Kernel variants")
-#ifndef JSG_X_WPB1024
-#define JSG_X_WPB1024 8
-#endif
 #ifndef JSG_X_ABL
 #define JSG_X_ABL 0
 #endif
-#ifndef JSG_X_PF
-#define JSG_X_PF 1
+#ifndef JSG_X_FPW1024      // frames per wavefront / wavefronts per workgroup of the 1024-point plan (A/B builds)
+#define JSG_X_FPW1024 1
 #endif
-using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, JSG_X_WPB1024, 1, 2, JSG_X_PF, JSG_X_ABL>;
-#ifdef JSG_DEV_VARIANTS
-// development variants of the 1024-point plan (selected with JSG_1024_VARIANT, see tools/sweep_variants.sh); compiled
-// only into development builds (JSG_DEV_VARIANTS=1 python -m jadespectrogram_amd._build)
-using Cfg1024B = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 2>;           // prefetch depth 2
-using Cfg1024G = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 1>;        // ablation: memory traffic only
-using Cfg1024H = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 2>;        // ablation: compute only
-using Cfg1024G1 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 0, 2, 1, 11>;      // memory-only sub-modes
-using Cfg1024G2 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 12>;
-using Cfg1024G3 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 13>;
-using Cfg1024G4 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 0, 2, 1, 14>;
-using Cfg1024S = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 3>;        // s_memtime stamps
-using Cfg1024N = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 0, false>; // cached (not non-temporal) stores
-using Cfg1024M = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 2, 1, 1, true>;
-// development variants of the 2048-point plan (JSG_2048_VARIANT)
-using Cfg2048T0 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 0, 1>;          // tables from global memory (L1/L2), no LDS copy
-using Cfg2048W8 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 8, 1, 2>;          // 8-wave workgroups
-using Cfg2048T0W8 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 8, 0, 2>;
+#ifndef JSG_X_WPB1024
+#define JSG_X_WPB1024 (8 / JSG_X_FPW1024)
+#endif
+#ifndef JSG_X_FPW2048
+#define JSG_X_FPW2048 1
 #endif
 #ifndef JSG_X_WPB2048
 #define JSG_X_WPB2048 4
@@ -253,7 +231,9 @@ using Cfg2048T0W8 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 8, 0, 2>;
 #ifndef JSG_X_WPS2048
 #define JSG_X_WPS2048 1
 #endif
-using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, JSG_X_WPB2048, 1, JSG_X_WPS2048>;   // (6-, 8- and 12-wave workgroups measured 4-60 % slower)
+using Cfg512 = Cfg<512, 8, 8, 4, 32, 36, 4, 33, 1, 8, 1, 2>;   // (a 80-VGPR budget = 3 workgroups per CU measured no faster)
+using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, JSG_X_WPB1024, 1, 2, JSG_X_FPW1024, JSG_X_ABL>;
+using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, JSG_X_WPB2048, 1, JSG_X_WPS2048, JSG_X_FPW2048>;   // (6-, 8-, 12-wave workgroups: no faster)
 using Cfg4096 = Cfg<4096, 16, 8, 16, 128, 144, 1, 272, 17, 4, 1, 1>;    // two wavefronts per frame, two frames per workgroup
 using Cfg8192 = Cfg<8192, 16, 16, 16, 256, 272, 1, 272, 17, 4, 0, 1>;   // four wavefronts per frame, one frame per workgroup
 // (frames of more than one wavefront exchange through the workgroup barrier, so every further frame in the workgroup joins
@@ -276,7 +256,7 @@ struct StftKArgs {
     int ring_w, ring_pos;
     int iters;
     const float2* tab;   // lane tables (Cfg::TAB_* layout): window pairs, stage-1 / stage-2 twiddles, post-pass twiddles
-    unsigned long long* stamps;   // development (ABL == 3): 4 s_memtime stamps per wave
+    unsigned long long* stamps;   // development (ABL == 3): s_memtime stamps per wave
     int xcd_remap;                // 1: XCD-aware block remap (default); 0: identity (development A/B)
     int chunked;                  // 0: grid-stride traversal (default); 1: one contiguous chunk per workgroup
     // OUTK == 1 (fused display path): the column leaves as 8-bit palette indices instead of dB floats
@@ -291,13 +271,6 @@ struct StftKArgs {
 // (<= 6e-8 relative) stays below half an ulp of the dB value, so no hi/lo split is spent on it.
 __device__ __forceinline__ float to_db(float p) {
     return __builtin_amdgcn_logf(p + 1e-11f) * 3.0102999566398120f;
-}
-
-// the same for two values: packed add and packed multiply (identical IEEE operations, half the issue slots)
-__device__ __forceinline__ cf to_db2(cf p) {
-    p = p + cf{1e-11f, 1e-11f};
-    cf r = {__builtin_amdgcn_logf(p.x), __builtin_amdgcn_logf(p.y)};
-    return r * cf{3.0102999566398120f, 3.0102999566398120f};
 }
 
 // CColorPalette::getRGBColor's index (reference CColorpalette.h:34-45), float32 arithmetic, truncation.
@@ -316,6 +289,8 @@ __device__ __forceinline__ float mix_combine(float acc, float pw) {
     else return pw;                                             // one channel per column: 0 + pw == pw exactly
 }
 
+#define GETREG_HW_ID ((32 - 1) << 11 | 4)   // s_getreg_b32 hwreg(HW_REG_HW_ID, 0, 32)
+
 // MIXOP: 0 sum over a channel range (AbsMean, Sum), 1 max, 2 min, 3 exactly one channel per column (mono, Left, Right,
 // per-channel): the channel bookkeeping folds away and every iteration ends in the store epilogue, which makes the
 // number of vector-memory instructions per iteration a compile-time fact -- the s_waitcnt the compiler places in
@@ -325,8 +300,8 @@ __device__ __forceinline__ float mix_combine(float acc, float pw) {
 // JSG_NO_LDS_MERGE: the backend's load/store optimizer fuses pairs of 8-byte LDS accesses into ds_read2_b64 /
 // ds_read2st64_b64.  On gfx950 a ds_read_b64 is serviced as 2 x 32 lanes (2 LDS cycles, 256 B/clk) but a ds_read2_b64 as
 // two accesses of 4 x 16 lanes (8 cycles, 128 B/clk) -- MI355X_MICROARCH.md, LDS table -- so the fused form halves the
-// read bandwidth of the exchange and table reads, which are the busiest pipe of this kernel.  The pass is switched
-// off for this kernel only.
+// read bandwidth of the exchange reads, on the busiest shared pipe of this kernel.  The pass is switched off for this
+// kernel only.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(JSG_X_LDS_MERGE)
 #define JSG_NO_LDS_MERGE __attribute__((target("no-load-store-opt")))
 #else
@@ -344,7 +319,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     const float* __restrict__ k_in, const long long k_in_pitch, const float2* __restrict__ k_tab, const unsigned k_n_frames,
     const unsigned k_first_frame, const int k_hop, const int k_flags, const unsigned k_c_range, const int k_iters,
     const unsigned k_nblk, const int k_feedblocks, const StftKArgs a_rest) {   // 14 dwords are preloaded; k_c_range = c_begin | c_end << 16
-    if constexpr (C::ABLX == 5) { if (k_iters != -12345) return; }   // ablation: launch cost of this kernel's resource footprint
+    if constexpr (C::ABL == 5) { if (k_iters != -12345) return; }   // ablation: launch cost of this kernel's resource footprint
     StftKArgs a = a_rest;
     a.in = k_in; a.in_pitch = k_in_pitch; a.n_frames = k_n_frames; a.first_frame = k_first_frame; a.hop = k_hop;
     a.iters = k_iters; a.regular = k_flags & 1; a.per_channel = (k_flags >> 1) & 1; a.c_begin = int(k_c_range & 0xffffu); a.c_end = int(k_c_range >> 16);
@@ -353,20 +328,21 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     // the compiler must assume that a table read may alias an exchange store and serialises them.
     __shared__ __attribute__((aligned(16))) cf s_tab[C::TLOC == 1 ? C::TAB_ELEMS : 2];
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int L = C::L, P = C::P, M = C::M, R1 = C::R1, R2 = C::R2, R3 = C::R3;
+    constexpr int L = C::L, P = C::P, M = C::M, R1 = C::R1, R2 = C::R2, R3 = C::R3, F = C::FPW;
     constexpr int U1 = C::U1, U2 = C::U2, U3 = C::U3;
+    typedef float v4f __attribute__((ext_vector_type(4)));
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps task math scalar
-    // frame slot inside the workgroup and lane index inside the frame (L lanes cooperate on one frame)
+    // frame slot inside the workgroup and lane index inside the frame (L lanes cooperate on one frame); a wavefront of an
+    // L <= 64 plan owns the SUB * F consecutive slots from slot0 on: slot0 + sub * F + f
     const int ll = L <= 64 ? lane % L : (wave % C::WPF) * 64 + lane;
     const int sub = L <= 64 ? lane / L : 0;
-    const int slot0 = L <= 64 ? wave * C::SUB : wave / C::WPF;   // wave-uniform part of the slot
-    cf* const lds = reinterpret_cast<cf*>(smem_raw) + (slot0 + sub) * C::LDS_ELEMS;
+    const int slot0 = L <= 64 ? wave * C::SUB * F : wave / C::WPF;   // wave-uniform part of the slot
+    cf* const lds0 = reinterpret_cast<cf*>(smem_raw) + (slot0 + sub * F) * C::LDS_ELEMS;   // frame f: lds0 + f * LDS_ELEMS
     constexpr int TL = C::TL;
     const int tl = L <= 64 ? lane : ll;                           // index into a lane-table row
-    unsigned long long st0 = 0, st1 = 0, st2 = 0, stA = 0, stB = 0, stC = 0;
-    unsigned long long rt0 = 0;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, stA = 0, stC = 0, stP = 0, rt0 = 0;
     if constexpr (C::ABL == 3) { st0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 
     // XCD-aware block remap (bijective): blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD one
@@ -387,13 +363,17 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     constexpr bool ONE = MIXOP == 3;
     const int nc = ONE ? 1 : c1 - c0;
     __builtin_assume(a.iters >= 1 && nc >= 1);   // (the launcher guarantees it) keeps the first frame's loads unconditional
-    const int n_fft = a.iters * nc;   // FFTs this wave performs, s = it*nc + (c - c0)
-    auto frame_src = [&](int s) -> const f2u* {
+    const int n_fft = a.iters * nc;   // FFT rounds this wave performs (F frames each), s = it*nc + (c - c0)
+    // task (= frame of the launch) of frame f of this lane in iteration `it`; tasks past the end are given the last frame
+    // again: they hold the same bits as that frame's own lanes and store them to the same column, so nothing is masked
+    auto task_of = [&](unsigned it, int f) -> unsigned {
+        unsigned t = task0 + it * task_stride + sub * F + f;
+        return t < a.n_frames ? t : a.n_frames - 1;
+    };
+    auto frame_src = [&](int s, int f) -> const f2u* {
         const unsigned it = (nc == 1) ? (unsigned)s : (unsigned)s / (unsigned)nc;
         const int c = c0 + (s - (int)it * nc);
-        unsigned t = task0 + it * task_stride + sub;
-        if (t >= a.n_frames) t = a.n_frames - 1;   // keep the lanes busy with a duplicate; its stores are masked
-        const unsigned j = a.first_frame + t;
+        const unsigned j = a.first_frame + task_of(it, f);
         long long start;
         if (a.regular) {
             start = (long long)j * a.hop;
@@ -404,109 +384,57 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         return reinterpret_cast<const f2u*>(a.in + (long long)c * a.in_pitch + start) + ll;
     };
 
-    // ---- lane tables first (L2-resident, 32 bytes per lane): their loads return before the frame's, so the
-    //      LDS staging and the workgroup barrier finish while the frame loads are still in flight ----
-    constexpr int NTL = C::TLOC == 1 ? (C::TAB_ELEMS / 2 + C::WPB * 64 - 1) / (C::WPB * 64) : 1;   // 16-byte table loads per thread
+    // ---- lane tables first: two 16-byte LDS-DMA pieces per thread bring the tables from L2 straight into LDS (wave-uniform
+    //      base + lane * 16 bytes, no VGPR round trip).  They are issued AHEAD of the frame loads: every wave's FFT start is
+    //      gated by the workgroup barrier behind the tables, so they are the latency-critical load (frame loads first, or
+    //      half of them first, measured 0.3-0.5 us slower per C2 launch) ----
+    constexpr int NTL = C::TLOC == 1 ? (C::TAB_ELEMS / 2 + C::WPB * 64 - 1) / (C::WPB * 64) : 1;   // 16-byte pieces per thread
     constexpr bool TAB_EVEN = (C::TAB_ELEMS / 2) % (C::WPB * 64) == 0;
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    v4f tabv[NTL];
-    unsigned long long stP = 0;
     if constexpr (C::ABL == 3) { asm volatile("" ::"s"(task0), "s"(task_stride)); stP = __builtin_readcyclecounter(); }
-    auto issue_table_loads = [&]() {
-#ifndef JSG_X_TABVGPR
-        // LDS-DMA: the table pieces go from L2 straight into LDS (wave-uniform base + lane * 16 bytes), no VGPR round trip
-        if constexpr (C::TLOC == 1) {
-            const v4f* g4 = reinterpret_cast<const v4f*>(a.tab) + threadIdx.x;
-            char* sbase = reinterpret_cast<char*>(s_tab) + wave * 1024;
-#pragma unroll
-            for (int i = 0; i < NTL; ++i)
-                if (TAB_EVEN || i + 1 < NTL || (int)threadIdx.x + i * C::WPB * 64 < C::TAB_ELEMS / 2)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g4 + i * C::WPB * 64),
-                                                     (__attribute__((address_space(3))) void*)(sbase + i * C::WPB * 1024), 16, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            return;
-        }
-#endif
-        if constexpr (C::TLOC == 1) {
-            const v4f* g4 = reinterpret_cast<const v4f*>(a.tab) + threadIdx.x;
-#pragma unroll
-            for (int i = 0; i < NTL; ++i)
-                if (TAB_EVEN || i + 1 < NTL || (int)threadIdx.x + i * C::WPB * 64 < C::TAB_ELEMS / 2) tabv[i] = g4[i * C::WPB * 64];
-            __builtin_amdgcn_sched_barrier(0);   // pin the order of the table loads against the frame loads (in-order vmcnt)
-        }
-    };
-#if !defined(JSG_X_FRAMES_FIRST) && !defined(JSG_X_SPLIT)
-    issue_table_loads();
-#endif
-    // ---- issue the loads of the first FFT(s) (software pipeline) ----
-    f2u rawA[P], rawB[C::PF == 2 ? P : 1];
-    if constexpr (C::ABL == 3) stA = __builtin_readcyclecounter();
-    if constexpr (C::PF > 0 && C::ABL != 2) {
-        const f2u* src = frame_src(0);
-#ifdef JSG_X_SPLIT
-        // first JSG_X_SPLIT frame loads, then the lane tables, then the rest: the tables still complete under
-        // s_waitcnt vmcnt(P - JSG_X_SPLIT) while part of the frame is already on its way
-#pragma unroll
-        for (int m = 0; m < JSG_X_SPLIT; ++m) rawA[m] = src[L * m];
-        __builtin_amdgcn_sched_barrier(0);
-        issue_table_loads();
-#pragma unroll
-        for (int m = JSG_X_SPLIT; m < P; ++m) rawA[m] = src[L * m];
-#else
-#pragma unroll
-        for (int m = 0; m < P; ++m) {
-            if ((C::ABLX == 12 || C::ABLX == 14) && m < P / 2) { rawA[m].x = 1.f; rawA[m].y = 2.f; }
-            else rawA[m] = src[L * m];
-        }
-#endif
-        if (C::PF == 2 && n_fft > 1) {
-            const f2u* src1 = frame_src(1);
-#pragma unroll
-            for (int m = 0; m < (C::PF == 2 ? P : 1); ++m) rawB[m] = src1[L * m];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#ifdef JSG_X_FRAMES_FIRST
-    issue_table_loads();
-#endif
-    const cf* tWin;
     if constexpr (C::TLOC == 1) {
-#ifndef JSG_X_TABVGPR
-        // the table pieces are older than the P frame loads of this wave: vmcnt(P) retires them and leaves the frame in flight
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (compiler only) the frame loads stay above the counted wait
-        if constexpr (C::PF > 0 && C::ABL != 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::PF == 2 ? 0 : P) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#else
-        v4f* s4 = reinterpret_cast<v4f*>(s_tab) + threadIdx.x;
+        const v4f* g4 = reinterpret_cast<const v4f*>(a.tab) + threadIdx.x;
+        char* sbase = reinterpret_cast<char*>(s_tab) + wave * 1024;
 #pragma unroll
         for (int i = 0; i < NTL; ++i)
-            if (TAB_EVEN || i + 1 < NTL || (int)threadIdx.x + i * C::WPB * 64 < C::TAB_ELEMS / 2) s4[i * C::WPB * 64] = tabv[i];
-        if constexpr (C::ABL == 3) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stB = __builtin_readcyclecounter(); }
-        __syncthreads();
-#endif
-        if constexpr (C::ABL == 3) stC = __builtin_readcyclecounter();
-        tWin = s_tab + tl;
-    } else {
-        tWin = reinterpret_cast<const cf*>(a.tab) + tl;
+            if (TAB_EVEN || i + 1 < NTL || (int)threadIdx.x + i * C::WPB * 64 < C::TAB_ELEMS / 2)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g4 + i * C::WPB * 64),
+                                                 (__attribute__((address_space(3))) void*)(sbase + i * C::WPB * 1024), 16, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // pin the order of the table pieces against the frame loads (in-order vmcnt)
     }
-    const cf* const tBase = tWin - tl;               // start of the tables (LDS copy, or global memory for TLOC == 0)
+    // ---- issue the loads of the first FFT round (software pipeline, one round ahead) ----
+    f2u raw[F][P];
+    if constexpr (C::ABL == 3) stA = __builtin_readcyclecounter();
+    if constexpr (C::ABL != 2) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const f2u* src = frame_src(0, f);
+#pragma unroll
+            for (int m = 0; m < P; ++m) raw[f][m] = src[L * m];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const cf* tBase;   // start of the tables (LDS copy, or global memory for TLOC == 0)
+    if constexpr (C::TLOC == 1) {
+        // the table pieces are older than the F * P frame loads of this wave: a counted vmcnt retires them and leaves the
+        // frames in flight (an LDS-DMA is a pending LDS write on the VM counter; __syncthreads() would drain everything)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (compiler only) the frame loads stay above the counted wait
+        if constexpr (C::ABL != 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(F * P) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if constexpr (C::ABL == 3) stC = __builtin_readcyclecounter();
+        tBase = s_tab;
+    } else {
+        tBase = reinterpret_cast<const cf*>(a.tab);
+    }
     const cf* const tTw1 = tBase + C::TAB_TW1;       // compact: [n2][TS1], not indexed by lane
     int tw1row[U1];                                   // row of this lane's butterfly u in the stage-1 table
 #pragma unroll
     for (int u = 0; u < U1; ++u) tw1row[u] = ((ll + L * u) / R3) * C::TS1;
-    static_assert(C::TLOC != 2, "lane tables in registers: removed (DESIGN.md, tried and measured)");
-    // value j of this lane from the [J][TL] table at `off`; with the pair layout an even j fetches j and j + 1 at once
-    auto tab1 = [&](int off, int j) -> cf { return tBase[off + C::tab_idx(j, tl)]; };
+    // values j and j + 1 (j even) of this lane from the [J][TL] table at `off`: one 16-byte read (pair layout)
     auto tab2 = [&](int off, int j, cf& a0, cf& a1) {
-        if constexpr (C::TABPAIR) {
-            const v4f q = *reinterpret_cast<const v4f*>(tBase + off + C::tab_idx(j, tl));
-            a0 = cf{q.x, q.y};
-            a1 = cf{q.z, q.w};
-        } else {
-            a0 = tab1(off, j);
-            a1 = tab1(off, j + 1);
-        }
+        const v4f q4 = *reinterpret_cast<const v4f*>(tBase + off + C::tab_idx(j, tl));
+        a0 = cf{q4.x, q4.y};
+        a1 = cf{q4.z, q4.w};
     };
     // exchange synchronisation: lock-step lanes of one wave need only a compiler fence; frames that span several
     // waves (L > 64) need the workgroup barrier (every wave of the workgroup runs the same number of them)
@@ -529,115 +457,135 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         e2r[w] = (t3 % R1) * C::AX + (t3 / R1) * C::AY;
     }
 
-    float acc[P];
-    float accNy;
+    float acc[F][P];
+    float accNy[F];
     constexpr float init = (MIXOP == 2) ? 1000000.0f : 0.0f;   // reference Spectrogram.cpp:69,78,86
 #pragma unroll
-    for (int m = 0; m < P; ++m) acc[m] = init;
-    accNy = init;
+    for (int f = 0; f < F; ++f) {
+#pragma unroll
+        for (int m = 0; m < P; ++m) acc[f][m] = init;
+        accNy[f] = init;
+    }
 
-    // One FFT of the sequence: consumes `raw` (loaded two FFTs ago), re-issues it for FFT s+2, transforms,
-    // accumulates |X|^2 into acc, and after the last channel of a column runs the mix epilogue + ring store.
-    // `last_tag` (std::true_type): the peeled final FFT of the wave, which prefetches nothing.  Peeling keeps the
-    // steady-state loop free of the "did the prefetch happen" merge (16 register moves per FFT and a full vmcnt(0)).
-    auto process = [&](auto& raw, int s, auto last_tag) {
+    // One FFT round of the sequence (F frames of one channel): consumes `raw` (loaded one round ago), re-issues it for
+    // round s+1, transforms, accumulates |X|^2 into acc, and after the last channel of a column runs the mix epilogue + ring
+    // store.  `last_tag` (std::true_type): the peeled final round of the wave, which prefetches nothing.  Peeling keeps
+    // the steady-state loop free of the "did the prefetch happen" merge (register moves and a full vmcnt(0)).
+    // Every stage loops over the F frames INSIDE the stage, in one basic block: the scheduler interleaves the frames'
+    // independent chains, and each table value is fetched once for all of them.
+    auto process = [&](int s, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
-        // ---- window multiply ----
-        cf x[P];
+        cf x[F][P];
         if constexpr (C::ABL == 2) {
 #pragma unroll
-            for (int m = 0; m < P; ++m) { raw[m].x = __int_as_float(0x3f800000 + lane + m + s); raw[m].y = 0.5f; }
-        }
-        if constexpr (C::PF == 0) {   // no software prefetch (large plans: registers are better spent on the data)
-            const f2u* src = frame_src(s);
+            for (int f = 0; f < F; ++f)
 #pragma unroll
-            for (int m = 0; m < P; ++m) raw[m] = src[L * m];
+                for (int m = 0; m < P; ++m) { raw[f][m].x = __int_as_float(0x3f800000 + lane + m + s + f); raw[f][m].y = 0.5f; }
         }
+        // ---- window multiply ----
 #pragma unroll
         for (int m = 0; m < P; m += 2) {
             cf w0, w1;
-            if constexpr (C::ABLX == 11 || C::ABLX == 14) w0 = w1 = cf{0.5f, 0.25f};
-            else tab2(C::TAB_WIN, m, w0, w1);
-            x[m] = to_cf(raw[m]) * w0;
-            x[m + 1] = to_cf(raw[m + 1]) * w1;
+            tab2(C::TAB_WIN, m, w0, w1);
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                x[f][m] = to_cf(raw[f][m]) * w0;
+                x[f][m + 1] = to_cf(raw[f][m + 1]) * w1;
+            }
         }
         if constexpr (C::ABL == 3) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (s == 0) st1 = __builtin_readcyclecounter();
         }
-        if (C::ABL != 2 && C::PF > 0 && !LAST && (C::PF == 1 || s + C::PF < n_fft)) {
-            const f2u* src = frame_src(s + C::PF);
+        if (C::ABL != 2 && !LAST) {   // the next round's frames travel while this one is transformed
 #pragma unroll
-            for (int m = 0; m < P; ++m) {
-                if ((C::ABLX == 12 || C::ABLX == 14) && m < P / 2) { raw[m].x = 1.f; raw[m].y = 2.f; }
-                else raw[m] = src[L * m];
+            for (int f = 0; f < F; ++f) {
+                const f2u* src = frame_src(s + 1, f);
+#pragma unroll
+                for (int m = 0; m < P; ++m) raw[f][m] = src[L * m];
             }
         }
         if constexpr (C::ABL == 1) {   // ablation: memory traffic only (results are meaningless)
 #pragma unroll
-            for (int m = 0; m < P; ++m) acc[m] += x[m].x * x[m].y;
-            accNy += x[0].x;
+            for (int f = 0; f < F; ++f) {
+#pragma unroll
+                for (int m = 0; m < P; ++m) acc[f][m] += x[f][m].x * x[f][m].y;
+                accNy[f] += x[f][0].x;
+            }
         }
         if constexpr (C::ABL != 1) {
         // ---- stage 1: radix-R1 over n1, twiddle W_{R1R2}^{n2 k1}, exchange 1 ----
 #pragma unroll
         for (int u = 0; u < U1; ++u) {
-            cf t[R1];
+            cf t[F][R1];
 #pragma unroll
-            for (int n1 = 0; n1 < R1; ++n1) t[n1] = x[u + U1 * n1];
-            dft<R1>(t);
-            lds[ll + L * u] = t[0];
-            if constexpr (C::TABPAIR) {   // row: k1 = 1, 2 | 3, 4 | ... | R1 - 1, (pad)
+            for (int f = 0; f < F; ++f) {
 #pragma unroll
-                for (int k1 = 1; k1 < R1; k1 += 2) {
-                    const v4f q = *reinterpret_cast<const v4f*>(tTw1 + tw1row[u] + k1 - 1);
-                    lds[k1 * C::S1 + ll + L * u] = cmul(t[k1], cf{q.x, q.y});
-                    if (k1 + 1 < R1) lds[(k1 + 1) * C::S1 + ll + L * u] = cmul(t[k1 + 1], cf{q.z, q.w});
+                for (int n1 = 0; n1 < R1; ++n1) t[f][n1] = x[f][u + U1 * n1];
+                dft<R1>(t[f]);
+                lds0[f * C::LDS_ELEMS + ll + L * u] = t[f][0];
+            }
+#pragma unroll
+            for (int k1 = 1; k1 < R1; k1 += 2) {   // row: k1 = 1, 2 | 3, 4 | ... | R1 - 1, (pad)
+                const v4f q4 = *reinterpret_cast<const v4f*>(tTw1 + tw1row[u] + k1 - 1);
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    lds0[f * C::LDS_ELEMS + k1 * C::S1 + ll + L * u] = cmul(t[f][k1], cf{q4.x, q4.y});
+                    if (k1 + 1 < R1) lds0[f * C::LDS_ELEMS + (k1 + 1) * C::S1 + ll + L * u] = cmul(t[f][k1 + 1], cf{q4.z, q4.w});
                 }
-            } else {
-#pragma unroll
-                for (int k1 = 1; k1 < R1; ++k1) lds[k1 * C::S1 + ll + L * u] = cmul(t[k1], tTw1[tw1row[u] + k1]);
             }
         }
         frame_sync();
 #pragma unroll
-        for (int v = 0; v < U2; ++v) {
+        for (int f = 0; f < F; ++f)
 #pragma unroll
-            for (int n2 = 0; n2 < R2; ++n2) x[v * R2 + n2] = lds[e1r[v] + n2 * R3];
-        }
+            for (int v = 0; v < U2; ++v) {
+#pragma unroll
+                for (int n2 = 0; n2 < R2; ++n2) x[f][v * R2 + n2] = lds0[f * C::LDS_ELEMS + e1r[v] + n2 * R3];
+            }
         frame_sync();
         // ---- stage 2: radix-R2 over n2, twiddle W_M^{n3 (k1 + R1 k2)}, exchange 2 ----
 #pragma unroll
         for (int v = 0; v < U2; ++v) {
-            cf t[R2];
+            cf t[F][R2];
 #pragma unroll
-            for (int n2 = 0; n2 < R2; ++n2) t[n2] = x[v * R2 + n2];
-            dft<R2>(t);
+            for (int f = 0; f < F; ++f) {
+#pragma unroll
+                for (int n2 = 0; n2 < R2; ++n2) t[f][n2] = x[f][v * R2 + n2];
+                dft<R2>(t[f]);
+            }
 #pragma unroll
             for (int k2 = 0; k2 < R2; k2 += 2) {
                 cf w0, w1;
                 tab2(C::TAB_TW2, v * R2 + k2, w0, w1);
-                lds[e2w[v] + k2 * C::AY] = cmul(t[k2], w0);
-                lds[e2w[v] + (k2 + 1) * C::AY] = cmul(t[k2 + 1], w1);
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    lds0[f * C::LDS_ELEMS + e2w[v] + k2 * C::AY] = cmul(t[f][k2], w0);
+                    lds0[f * C::LDS_ELEMS + e2w[v] + (k2 + 1) * C::AY] = cmul(t[f][k2 + 1], w1);
+                }
             }
         }
         frame_sync();
         // ---- stage 3: radix-R3 over n3; Z[k], k = t3 + R1 R2 k3 ----
 #pragma unroll
-        for (int w = 0; w < U3; ++w) {
+        for (int f = 0; f < F; ++f)
 #pragma unroll
-            for (int n3 = 0; n3 < R3; ++n3) x[w * R3 + n3] = lds[e2r[w] + n3 * C::AZ];
-        }
+            for (int w = 0; w < U3; ++w) {
+#pragma unroll
+                for (int n3 = 0; n3 < R3; ++n3) x[f][w * R3 + n3] = lds0[f * C::LDS_ELEMS + e2r[w] + n3 * C::AZ];
+            }
         frame_sync();
 #pragma unroll
-        for (int w = 0; w < U3; ++w) {
-            cf t[R3];
+        for (int f = 0; f < F; ++f)
 #pragma unroll
-            for (int n3 = 0; n3 < R3; ++n3) t[n3] = x[w * R3 + n3];
-            dft<R3>(t);
+            for (int w = 0; w < U3; ++w) {
+                cf t[R3];
 #pragma unroll
-            for (int k3 = 0; k3 < R3; ++k3) x[w * R3 + k3] = t[k3];
-        }
+                for (int n3 = 0; n3 < R3; ++n3) t[n3] = x[f][w * R3 + n3];
+                dft<R3>(t);
+#pragma unroll
+                for (int k3 = 0; k3 < R3; ++k3) x[f][w * R3 + k3] = t[k3];
+            }
         {
             // ---- paired real-split post pass.  Bin k = ll + L*rho (rho = w + U3*k3).  A lane owns the pairs of its
             // lower registers rho < P/2: (k, M-k); Z[M-k] is the upper register P-1-rho of lane L-ll (lane 0: its own
@@ -647,38 +595,46 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
             // acc[P/2 + j] = |X[M - ll - L j]|^2, accNy = |X[M/2]|^2.
             auto reg_of = [](int rho) { return (rho % U3) * R3 + rho / U3; };
 #pragma unroll
-            for (int rho = P / 2; rho < P; ++rho) lds[ll + L * rho] = x[reg_of(rho)];
-            if (ll == 0) lds[M] = x[0];   // Z[M] := Z[0]
-            frame_sync();
-            cf zq[P / 2];
+            for (int f = 0; f < F; ++f) {
 #pragma unroll
-            for (int rho = 0; rho < P / 2; ++rho) zq[rho] = lds[M - (ll + L * rho)];
-            frame_sync();   // the next FFT's exchange stores must stay behind these loads
+                for (int rho = P / 2; rho < P; ++rho) lds0[f * C::LDS_ELEMS + ll + L * rho] = x[f][reg_of(rho)];
+                if (ll == 0) lds0[f * C::LDS_ELEMS + M] = x[f][0];   // Z[M] := Z[0]
+            }
+            frame_sync();
+            cf zq[F][P / 2];
+#pragma unroll
+            for (int f = 0; f < F; ++f)
+#pragma unroll
+                for (int rho = 0; rho < P / 2; ++rho) zq[f][rho] = lds0[f * C::LDS_ELEMS + M - (ll + L * rho)];
+            frame_sync();   // the next round's exchange stores must stay behind these loads
             cf wpost[P / 2];
 #pragma unroll
             for (int rho = 0; rho < P / 2; rho += 2) tab2(C::TAB_POST, rho, wpost[rho], wpost[rho + 1]);
 #pragma unroll
-            for (int rho = 0; rho < P / 2; ++rho) {
-                const cf z = x[reg_of(rho)], p = zq[rho];
-                const cf S = add_conj(z, p);
-                const cf T = cmul(sub_conj(z, p), wpost[rho]);
-                const cf xa = S + T, xb = S - T;
-                acc[rho] = mix_combine<MIXOP>(acc[rho], xa.x * xa.x + xa.y * xa.y);
-                acc[P / 2 + rho] = mix_combine<MIXOP>(acc[P / 2 + rho], xb.x * xb.x + xb.y * xb.y);
-            }
-            {   // bin M/2 (held by the frame's lane 0): the window carries 1/2, so |X|^2 = 4 |Z'|^2.  For single-wave
-                // frames the value is broadcast so that every lane can take part in an unmasked store below.
-                cf z = x[reg_of(P / 2)];
-                if constexpr (L == 64) {
-                    z.x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(z.x)));
-                    z.y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(z.y)));
-                } else if constexpr (L == 32) {
-                    const int ax = __builtin_amdgcn_readlane(__float_as_int(z.x), 0), bx = __builtin_amdgcn_readlane(__float_as_int(z.x), 32);
-                    const int ay = __builtin_amdgcn_readlane(__float_as_int(z.y), 0), by = __builtin_amdgcn_readlane(__float_as_int(z.y), 32);
-                    z.x = __int_as_float(sub ? bx : ax);
-                    z.y = __int_as_float(sub ? by : ay);
+            for (int f = 0; f < F; ++f) {
+#pragma unroll
+                for (int rho = 0; rho < P / 2; ++rho) {
+                    const cf z = x[f][reg_of(rho)], p = zq[f][rho];
+                    const cf S = add_conj(z, p);
+                    const cf T = cmul(sub_conj(z, p), wpost[rho]);
+                    const cf xa = S + T, xb = S - T;
+                    acc[f][rho] = mix_combine<MIXOP>(acc[f][rho], xa.x * xa.x + xa.y * xa.y);
+                    acc[f][P / 2 + rho] = mix_combine<MIXOP>(acc[f][P / 2 + rho], xb.x * xb.x + xb.y * xb.y);
                 }
-                accNy = mix_combine<MIXOP>(accNy, 4.0f * (z.x * z.x + z.y * z.y));
+                {   // bin M/2 (held by the frame's lane 0): the window carries 1/2, so |X|^2 = 4 |Z'|^2.  For single-wave
+                    // frames the value is broadcast so that every lane can take part in an unmasked store below.
+                    cf z = x[f][reg_of(P / 2)];
+                    if constexpr (L == 64) {
+                        z.x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(z.x)));
+                        z.y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(z.y)));
+                    } else if constexpr (L == 32) {
+                        const int ax = __builtin_amdgcn_readlane(__float_as_int(z.x), 0), bx = __builtin_amdgcn_readlane(__float_as_int(z.x), 32);
+                        const int ay = __builtin_amdgcn_readlane(__float_as_int(z.y), 0), by = __builtin_amdgcn_readlane(__float_as_int(z.y), 32);
+                        z.x = __int_as_float(sub ? bx : ax);
+                        z.y = __int_as_float(sub ? by : ay);
+                    }
+                    accNy[f] = mix_combine<MIXOP>(accNy[f], 4.0f * (z.x * z.x + z.y * z.y));
+                }
             }
         }
         }   // ABL != 1
@@ -686,104 +642,64 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         // ---- last channel of this column: mix epilogue + dB + ring store ----
         const unsigned it = (nc == 1) ? (unsigned)s : (unsigned)s / (unsigned)nc;
         if (ONE || s - (int)it * nc == nc - 1) {
-            // Tasks past the end of the launch were given frame n_frames-1 again (frame_src): they hold the same
-            // bits as that frame's own wave and store them to the same column, so the stores need no mask.
-            unsigned t = task0 + it * task_stride + sub;
-            if (t >= a.n_frames) t = a.n_frames - 1;
-            unsigned col = a.ring_pos + t;                     // n_frames <= ring_w (checked by the launcher)
-            if (col >= (unsigned)a.ring_w) col -= a.ring_w;
-            float* dst = a.out + (long long)col * a.out_pitch + (a.per_channel ? (long long)c0 * a.out_cpitch : 0ll);
             if constexpr (C::ABL == 3) { if (s == 0) st2 = __builtin_readcyclecounter(); }
-            if constexpr (ONE) {
-                // one channel: the launcher selects this instantiation only when the mix scale is exactly 1
-            } else
-            if (a.exact_div) {   // m_powerfinal[kk] /= m_channels (Spectrogram.cpp:74), IEEE division
 #pragma unroll
-                for (int m = 0; m < P; ++m) acc[m] = acc[m] / a.divisor;
-                accNy = accNy / a.divisor;
-            } else if (a.scale != 1.0f) {   // power-of-two channel count: the same division as an exact scaling
+            for (int f = 0; f < F; ++f) {
+                unsigned col = a.ring_pos + task_of(it, f);        // n_frames <= ring_w (checked by the launcher)
+                if (col >= (unsigned)a.ring_w) col -= a.ring_w;
+                if constexpr (ONE) {
+                    // one channel: the launcher selects this instantiation only when the mix scale is exactly 1
+                } else
+                if (a.exact_div) {   // m_powerfinal[kk] /= m_channels (Spectrogram.cpp:74), IEEE division
 #pragma unroll
-                for (int m = 0; m < P; ++m) acc[m] *= a.scale;
-                accNy *= a.scale;
-            }
-            if (!a.linear) {
-#ifdef JSG_X_PKDB
+                    for (int m = 0; m < P; ++m) acc[f][m] = acc[f][m] / a.divisor;
+                    accNy[f] = accNy[f] / a.divisor;
+                } else if (a.scale != 1.0f) {   // power-of-two channel count: the same division as an exact scaling
 #pragma unroll
-                for (int m = 0; m < P; m += 2) {
-                    const cf d = to_db2(cf{acc[m], acc[m + 1]});
-                    acc[m] = d.x;
-                    acc[m + 1] = d.y;
+                    for (int m = 0; m < P; ++m) acc[f][m] *= a.scale;
+                    accNy[f] *= a.scale;
                 }
-#else
+                if (!a.linear) {
 #pragma unroll
-                for (int m = 0; m < P; ++m) acc[m] = to_db(acc[m]);
-#endif
-                accNy = to_db(accNy);
-            }
-            if constexpr (OUTK == 1) {
-                // palette index of every bin; 64 consecutive bytes of the index column per store instruction
-                unsigned char* ic = a.idx + (long long)col * a.idx_pitch;
-#pragma unroll
-                for (int rho = 0; rho < P / 2; ++rho) {
-                    ic[ll + L * rho] = (unsigned char)color_index(acc[rho], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
-                    ic[M - (ll + L * rho)] = (unsigned char)color_index(acc[P / 2 + rho], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
+                    for (int m = 0; m < P; ++m) acc[f][m] = to_db(acc[f][m]);
+                    accNy[f] = to_db(accNy[f]);
                 }
-                if (L <= 64 || ll == 0) ic[M / 2] = (unsigned char)color_index(accNy, a.vmin, a.vmax, a.top, a.mult, a.n_colors);
-            } else
-            if constexpr (C::ABLX == 13 || C::ABLX == 14) {
-                // ablation: the same bytes as two 16-byte stores per lane (results meaningless)
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                {
-                    v4f* d4 = reinterpret_cast<v4f*>(dst);
-                    v4f v0 = {acc[0], acc[1], acc[2], acc[3]}, v1 = {acc[4], acc[5], acc[6], acc[7]};
-                    __builtin_nontemporal_store(v0, &d4[ll]);
-                    __builtin_nontemporal_store(v1, &d4[64 + ll]);
-                    if (ll == 0) __builtin_nontemporal_store(accNy, &dst[M]);
-                }
-            } else {
-                if (C::ABL == 2 ? (acc[0] == 12345.678f) : true) {
+                if constexpr (OUTK == 1) {
+                    // palette index of every bin; 64 consecutive bytes of the index column per store instruction
+                    unsigned char* ic = a.idx + (long long)col * a.idx_pitch;
 #pragma unroll
                     for (int rho = 0; rho < P / 2; ++rho) {
-                        if constexpr (C::NT) {
-                            __builtin_nontemporal_store(acc[rho], &dst[ll + L * rho]);
-                            __builtin_nontemporal_store(acc[P / 2 + rho], &dst[M - (ll + L * rho)]);
-                        } else {
-                            dst[ll + L * rho] = acc[rho];
-                            dst[M - (ll + L * rho)] = acc[P / 2 + rho];
-                        }
+                        ic[ll + L * rho] = (unsigned char)color_index(acc[f][rho], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
+                        ic[M - (ll + L * rho)] = (unsigned char)color_index(acc[f][P / 2 + rho], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
                     }
-                    if (L <= 64 || ll == 0) {   // L <= 64: accNy is uniform over the frame's lanes
-                        if constexpr (C::NT) __builtin_nontemporal_store(accNy, &dst[M / 2]);
-                        else dst[M / 2] = accNy;
-                    }
-                }
-            }
+                    if (L <= 64 || ll == 0) ic[M / 2] = (unsigned char)color_index(accNy[f], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
+                } else if (C::ABL == 2 ? (acc[f][0] == 12345.678f) : true) {
+                    // non-temporal dword stores, 256 contiguous bytes of the column per instruction (streaming the columns out
+                    // instead of leaving them dirty in L2 removed the end-of-kernel write-back)
+                    float* dst = a.out + (long long)col * a.out_pitch + (a.per_channel ? (long long)c0 * a.out_cpitch : 0ll);
 #pragma unroll
-            for (int m = 0; m < P; ++m) acc[m] = init;
-            accNy = init;
+                    for (int rho = 0; rho < P / 2; ++rho) {
+                        __builtin_nontemporal_store(acc[f][rho], &dst[ll + L * rho]);
+                        __builtin_nontemporal_store(acc[f][P / 2 + rho], &dst[M - (ll + L * rho)]);
+                    }
+                    if (L <= 64 || ll == 0) __builtin_nontemporal_store(accNy[f], &dst[M / 2]);   // L <= 64: uniform over the frame's lanes
+                }
+#pragma unroll
+                for (int m = 0; m < P; ++m) acc[f][m] = init;
+                accNy[f] = init;
+            }
         }
     };
 
-    if constexpr (C::PF == 2) {
-        for (int s = 0; s < n_fft; s += 2) {
-            process(rawA, s, std::false_type{});
-            if (s + 1 < n_fft) process(rawB, s + 1, std::false_type{});
-        }
-    } else if constexpr (C::PF == 1) {
-        if (n_fft > 0) {
-            for (int s = 0; s + 1 < n_fft; ++s) process(rawA, s, std::false_type{});
-            process(rawA, n_fft - 1, std::true_type{});
-        }
-    } else {
-        for (int s = 0; s < n_fft; ++s) process(rawA, s, std::true_type{});
-    }
+    for (int s = 0; s + 1 < n_fft; ++s) process(s, std::false_type{});
+    process(n_fft - 1, std::true_type{});
     if constexpr (C::ABL == 3) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long st3 = __builtin_readcyclecounter();
         if (lane == 0 && a.stamps) {
             unsigned long long* d = a.stamps + (size_t)(blockIdx.x * C::WPB + wave) * 10;
             d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3; d[4] = rt0; d[5] = __builtin_amdgcn_s_memrealtime();
-            d[6] = stA; d[7] = stB; d[8] = stC; d[9] = stP;
+            d[6] = stA; d[7] = 0; d[8] = stC; d[9] = stP;
         }
     }
 }
@@ -901,8 +817,8 @@ static void fill_tables(std::vector<float2>& t, const float* window, double amp)
     for (int n2 = 0; n2 < R2; ++n2)   // stage-1 twiddles, one row per n2 (shared by the lanes with t1 / R3 == n2)
         for (int k1 = 0; k1 < R1; ++k1) {
             const double ang = -two_pi * double((long long)n2 * k1 % (R1 * R2)) / double(R1 * R2);
-            if (C::TABPAIR && k1 == 0) continue;   // the twiddle of k1 = 0 is 1 and never read
-            t[C::TAB_TW1 + n2 * C::TS1 + (C::TABPAIR ? k1 - 1 : k1)] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
+            if (k1 == 0) continue;   // the twiddle of k1 = 0 is 1 and never read; k1 sits at column k1 - 1
+            t[C::TAB_TW1 + n2 * C::TS1 + k1 - 1] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
         }
     for (int e = 0; e < TL; ++e) {   // entry e of a table row belongs to lane-in-frame ll (L = 32: both half-waves)
         const int ll = e % L;
@@ -1214,15 +1130,6 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
         case 4096: tpb = Cfg4096::TPB; break;
         case 8192: tpb = Cfg8192::TPB; break;
     }
-    static const int v1024 = [] { const char* e = getenv("JSG_1024_VARIANT"); return e ? e[0] : '-'; }();
-    static const int v2048 = [] { const char* e = getenv("JSG_2048_VARIANT"); return e ? e[0] : '-'; }();
-#ifdef JSG_DEV_VARIANTS
-    if (plan->n == 2048 && (v2048 == 'W' || v2048 == 'X')) tpb = Cfg2048W8::TPB;
-#else
-    if (v1024 != '-' || v2048 != '-')
-        return jsg_fail(JSG_ERR_UNSUPPORTED, "JSG_1024_VARIANT / JSG_2048_VARIANT need a development build of libjsg.so "
-                                             "(JSG_DEV_VARIANTS=1 python -m jadespectrogram_amd._build)");
-#endif
     const long long want = (g->n_frames + tpb - 1) / tpb;
     const int ny = ka.per_channel ? g->channels : 1;
     if (ny > 65535) return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_db_launch: more than 65535 channels in per-channel mode");
@@ -1243,35 +1150,8 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     hipError_t err = hipSuccess;
     switch (plan->n) {
         case 512: err = launch_stft<Cfg512>(ka, mixop, grid, s); break;
-        case 1024: {
-            switch (v1024) {
-#ifdef JSG_DEV_VARIANTS
-                case 'B': err = launch_stft<Cfg1024B>(ka, mixop, grid, s); break;
-                case 'G': err = launch_stft<Cfg1024G>(ka, mixop, grid, s); break;
-                case 'H': err = launch_stft<Cfg1024H>(ka, mixop, grid, s); break;
-                case '1': err = launch_stft<Cfg1024G1>(ka, mixop, grid, s); break;
-                case '2': err = launch_stft<Cfg1024G2>(ka, mixop, grid, s); break;
-                case '3': err = launch_stft<Cfg1024G3>(ka, mixop, grid, s); break;
-                case '4': err = launch_stft<Cfg1024G4>(ka, mixop, grid, s); break;
-                case 'S': err = launch_stft<Cfg1024S>(ka, mixop, grid, s); break;
-                case 'N': err = launch_stft<Cfg1024N>(ka, mixop, grid, s); break;
-                case 'M': err = launch_stft<Cfg1024M>(ka, mixop, grid, s); break;
-#endif
-                default: err = launch_stft<Cfg1024>(ka, mixop, grid, s); break;
-            }
-            break;
-        }
-        case 2048: {
-            switch (v2048) {
-#ifdef JSG_DEV_VARIANTS
-                case 'T': err = launch_stft<Cfg2048T0>(ka, mixop, grid, s); break;
-                case 'W': err = launch_stft<Cfg2048W8>(ka, mixop, grid, s); break;
-                case 'X': err = launch_stft<Cfg2048T0W8>(ka, mixop, grid, s); break;
-#endif
-                default: err = launch_stft<Cfg2048>(ka, mixop, grid, s); break;
-            }
-            break;
-        }
+        case 1024: err = launch_stft<Cfg1024>(ka, mixop, grid, s); break;
+        case 2048: err = launch_stft<Cfg2048>(ka, mixop, grid, s); break;
         case 4096: err = launch_stft<Cfg4096>(ka, mixop, grid, s); break;
         case 8192: err = launch_stft<Cfg8192>(ka, mixop, grid, s); break;
     }
