@@ -311,10 +311,31 @@ def main():
                 launch(b, one.cuda_stream)
             torch.cuda.synchronize()
         if args.no_graph:
+            # Host-issued launches, but BACK TO BACK on the GPU: a gate kernel (torch.cuda._sleep: spins for a fixed number of
+            # cycles, i.e. it always ends) holds the stream while the host enqueues the whole group behind it.  Under rocprofv3
+            # the host needs ~11 us per launch; without the gate every dispatch would start on an idle GPU and read 1 us longer.
+            with torch.cuda.stream(one):
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record(one); torch.cuda._sleep(20_000_000); g1.record(one)
+                torch.cuda.synchronize()
+            gate = {"cycles_per_ms": 20_000_000 / max(g0.elapsed_time(g1), 1e-3), "cycles": 0}
+
+            def gated(issue):
+                def run():
+                    with torch.cuda.stream(one):
+                        if gate["cycles"]:
+                            torch.cuda._sleep(gate["cycles"])
+                        t_i = time.perf_counter()
+                        issue()
+                        t_i = (time.perf_counter() - t_i) * 1e3
+                    # next time the gate outlasts the host's issue time by half (bounded: at most 0.5 s)
+                    gate["cycles"] = int(min(500.0, 1.5 * t_i + 0.2) * gate["cycles_per_ms"])
+                return run
             if c["colour"]:
-                def replay_inorder():
+                def _issue():
                     for i in range(lps):
                         launch(i % nbuf, one.cuda_stream)
+                replay_inorder = gated(_issue)
             else:
                 arr1 = (capi.StftArgs * lps)()
                 for i in range(lps):
@@ -322,8 +343,7 @@ def main():
                     ctypes.memmove(ctypes.byref(arr1, i * ctypes.sizeof(capi.StftArgs)), ctypes.byref(a_i), ctypes.sizeof(capi.StftArgs))
                 one_arr = (ctypes.c_void_p * 1)(one.cuda_stream)
 
-                def replay_inorder():
-                    capi.check(lib.jsg_stft_db_launch_many(plan._p, arr1, lps, one_arr, 1))
+                replay_inorder = gated(lambda: capi.check(lib.jsg_stft_db_launch_many(plan._p, arr1, lps, one_arr, 1)))
         else:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.stream(one):
@@ -378,13 +398,30 @@ def main():
         reps = max(3, min(args.steps, 20))
         replay_inorder(); torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        with torch.cuda.stream(one):
-            ev0.record(one)
+        if args.no_graph:   # the gate is part of replay_inorder(): the events go between the gate and the launches
+            tot = 0.0
             for _ in range(reps):
-                replay_inorder()
-            ev1.record(one)
-        torch.cuda.synchronize()
-        inorder_us = ev0.elapsed_time(ev1) * 1e3 / (reps * lps)
+                with torch.cuda.stream(one):
+                    if gate["cycles"]:
+                        torch.cuda._sleep(gate["cycles"])
+                    ev0.record(one)
+                    if c["colour"]:
+                        for i in range(lps):
+                            launch(i % nbuf, one.cuda_stream)
+                    else:
+                        capi.check(lib.jsg_stft_db_launch_many(plan._p, arr1, lps, one_arr, 1))
+                    ev1.record(one)
+                torch.cuda.synchronize()
+                tot += ev0.elapsed_time(ev1)
+            inorder_us = tot * 1e3 / (reps * lps)
+        else:
+            with torch.cuda.stream(one):
+                ev0.record(one)
+                for _ in range(reps):
+                    replay_inorder()
+                ev1.record(one)
+            torch.cuda.synchronize()
+            inorder_us = ev0.elapsed_time(ev1) * 1e3 / (reps * lps)
         if not c["colour"] and not args.no_graph:   # host-issued launches on the same stream, for comparison (adds the runtime's per-launch handling)
             k = min(lps, 512)
             with torch.cuda.stream(one):
@@ -436,7 +473,7 @@ def main():
                    "step": f"{lps} launches x {F} {'columns' if c['colour'] or C > 1 else 'frames'} = {lps * units_per_launch} {c['unit'].split('/')[0]} per step and GPU",
                    "launches_per_step": lps, "frames_per_launch": F * C, "columns_per_launch": F, "channels_per_gpu": C,
                    "distinct_batches": nbuf, "hip_streams_per_gpu": n_streams,
-                   "issue": (("host-issued, in order on one stream" if args.no_graph else "hipGraph replay, in order") if n_streams == 1 else f"one C call per step, {max(1, args.issue_threads)} host thread(s)"),
+                   "issue": (("host-issued behind a gate kernel, in order and back to back on one stream (the gate is inside the timed region: this mode is for the tracer)" if args.no_graph else "hipGraph replay, in order") if n_streams == 1 else f"one C call per step, {max(1, args.issue_threads)} host thread(s)"),
                    "prewarm_s": round(prewarm_s, 3),
                    "parallelism": f"{world} GPU(s), independent batches, no data-path collective"},
     }
