@@ -211,6 +211,8 @@ def main():
     ap.add_argument("--issue-threads", type=int, default=2, help="host threads issuing the launches of a step (c2, streams > 1)")
     ap.add_argument("--blocks-per-cu", type=int, default=1, help="workgroups per CU of each launch when launches overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gate", action="store_true", help="with --no-graph: hold the stream with a gate kernel while the host enqueues a step's "
+                                                        "launches, so that they run back to back even under a tracer (short kernels: c2)")
     ap.add_argument("--no-graph", action="store_true", help="issue the in-order launches from the host instead of replaying a hipGraph "
                                                             "(rocprofv3 does not see kernels inside graph replays, and its counter passes crash on them)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work at all: exercises the N-rank plumbing (barriers, reductions, "
@@ -311,9 +313,11 @@ def main():
                 launch(b, one.cuda_stream)
             torch.cuda.synchronize()
         if args.no_graph:
-            # Host-issued launches, but BACK TO BACK on the GPU: a gate kernel (torch.cuda._sleep: spins for a fixed number of
-            # cycles, i.e. it always ends) holds the stream while the host enqueues the whole group behind it.  Under rocprofv3
-            # the host needs ~11 us per launch; without the gate every dispatch would start on an idle GPU and read 1 us longer.
+            # Host-issued launches (rocprofv3 does not see kernels inside graph replays).  --gate: BACK TO BACK on the GPU all the
+            # same -- a gate kernel (torch.cuda._sleep: spins for a fixed number of cycles, i.e. it always ends) holds the stream
+            # while the host enqueues the whole group behind it.  Under rocprofv3 the host needs ~11 us per launch; without the
+            # gate every 5 us dispatch of c2 starts on an idle GPU and reads ~1 us longer (6.3 vs 5.7 us).  For the long kernels
+            # of c3 / c5 the tracer's own per-dispatch work shows up instead when they run back to back, so they are traced ungated.
             with torch.cuda.stream(one):
                 g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 g0.record(one); torch.cuda._sleep(20_000_000); g1.record(one)
@@ -323,7 +327,7 @@ def main():
             def gated(issue):
                 def run():
                     with torch.cuda.stream(one):
-                        if gate["cycles"]:
+                        if gate["cycles"] and args.gate:
                             torch.cuda._sleep(gate["cycles"])
                         t_i = time.perf_counter()
                         issue()
@@ -402,7 +406,7 @@ def main():
             tot = 0.0
             for _ in range(reps):
                 with torch.cuda.stream(one):
-                    if gate["cycles"]:
+                    if gate["cycles"] and args.gate:
                         torch.cuda._sleep(gate["cycles"])
                     ev0.record(one)
                     if c["colour"]:
@@ -473,7 +477,7 @@ def main():
                    "step": f"{lps} launches x {F} {'columns' if c['colour'] or C > 1 else 'frames'} = {lps * units_per_launch} {c['unit'].split('/')[0]} per step and GPU",
                    "launches_per_step": lps, "frames_per_launch": F * C, "columns_per_launch": F, "channels_per_gpu": C,
                    "distinct_batches": nbuf, "hip_streams_per_gpu": n_streams,
-                   "issue": (("host-issued behind a gate kernel, in order and back to back on one stream (the gate is inside the timed region: this mode is for the tracer)" if args.no_graph else "hipGraph replay, in order") if n_streams == 1 else f"one C call per step, {max(1, args.issue_threads)} host thread(s)"),
+                   "issue": ((("host-issued behind a gate kernel, in order and back to back on one stream (the gate is inside the timed region: this mode is for the tracer)" if args.gate else "host-issued, in order on one stream") if args.no_graph else "hipGraph replay, in order") if n_streams == 1 else f"one C call per step, {max(1, args.issue_threads)} host thread(s)"),
                    "prewarm_s": round(prewarm_s, 3),
                    "parallelism": f"{world} GPU(s), independent batches, no data-path collective"},
     }
