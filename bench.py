@@ -226,13 +226,13 @@ def main():
     import torch
 
     # child processes (git, and make if the C oracle is stale) are started BEFORE anything initialises the GPU
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
     commit = _git_commit()
-    if not args.dry_run and not args.no_cpu_baseline:
+    if not args.dry_run and not args.no_cpu_baseline and world == 1:   # the CPU baseline leg runs at N = 1 only
         from oracle import oracle_c
         oracle_c.load()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"

@@ -340,7 +340,6 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     const int sub = L <= 64 ? lane / L : 0;
     const int slot0 = L <= 64 ? wave * C::SUB * F : wave / C::WPF;   // wave-uniform part of the slot
     cf* const lds0 = reinterpret_cast<cf*>(smem_raw) + (slot0 + sub * F) * C::LDS_ELEMS;   // frame f: lds0 + f * LDS_ELEMS
-    constexpr int TL = C::TL;
     const int tl = L <= 64 ? lane : ll;                           // index into a lane-table row
     unsigned long long st0 = 0, st1 = 0, st2 = 0, stA = 0, stC = 0, stP = 0, rt0 = 0;
     if constexpr (C::ABL == 3) { st0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
