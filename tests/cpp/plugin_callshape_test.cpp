@@ -107,6 +107,7 @@ int main() {
     int arg = 0;
     for (int k = 1; k < H; ++k)
         if (gui.m_displaymem[size_t(newest)][size_t(k)] > gui.m_displaymem[size_t(newest)][size_t(arg)]) arg = k;
+    if (proc.m_spectrogram.getSamplerate() != 48000.f) return 4;   // SpectrogramComponent::paint, reference Spectrogram.cpp:439
     // an unsupported size must not throw out of a GUI callback
     proc.m_spectrogram.setFFTSize(1000);
     std::printf("{\"W\": %d, \"H\": %d, \"new_between_ticks\": %d, \"new_after_resize\": %d, \"peak_bin\": %d, \"peak_db\": %.4f, "
