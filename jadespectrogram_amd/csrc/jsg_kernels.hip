@@ -182,7 +182,8 @@ struct Cfg {
     static constexpr int SUB = L < 64 ? 64 / L : 1;  // frames side by side in one wavefront (L = 32: two)
     static constexpr int WPF = L > 64 ? L / 64 : 1;  // wavefronts per frame (L = 128, 256: the exchanges use s_barrier)
     static constexpr int FPW = FPW_;                 // frames interleaved in one wavefront's instruction stream
-    static constexpr int TL = L > 64 ? L : 64;       // entries per lane-table row
+    static constexpr int TL = L;                     // entries per lane-table row (L = 32: both half-waves read the same entries)
+    static constexpr bool TWO_STAGE = R3_ == 1;      // R1 * R2 = M: one exchange, the second radix stage leaves bin ll + L*k2 in register k2
     static constexpr int WPB = WPB_;                 // wavefronts per workgroup
     static constexpr int TPB = WPB * 64 / L * FPW;   // frames per workgroup per iteration
     static constexpr int TLOC = TLOC_;
@@ -196,11 +197,11 @@ struct Cfg {
     // [J][TL] table is stored at ((j / 2) * TL + e) * 2 + j % 2.  Stage-1 rows hold k1 = 1.. at column k1 - 1, row stride
     // R1 + 2 (16-byte aligned rows whose 16-byte chunks fall into different banks for the n2 groups of a wave).
     static constexpr int TS1 = R1_ + 2;
-    static constexpr int tab_idx(int j, int e) { return ((j / 2) * (L_ > 64 ? L_ : 64) + e) * 2 + j % 2; }
-    static constexpr int TAB_WIN = 0, TAB_TW1 = P * TL, TAB_TW2 = TAB_TW1 + R2_ * TS1, TAB_POST = TAB_TW2 + P * TL;
+    static constexpr int tab_idx(int j, int e) { return ((j / 2) * L_ + e) * 2 + j % 2; }
+    static constexpr int TAB_WIN = 0, TAB_TW1 = P * TL, TAB_TW2 = TAB_TW1 + R2_ * TS1, TAB_POST = TAB_TW2 + (TWO_STAGE ? 0 : P * TL);
     static constexpr int TAB_ELEMS = TAB_POST + (P / 2) * TL;
     static constexpr int e1max = (R1 - 1) * S1 + M / R1;
-    static constexpr int e2max = (R1 - 1) * AX + (R2 - 1) * AY + (R3 - 1) * AZ + 1;
+    static constexpr int e2max = TWO_STAGE ? 0 : (R1 - 1) * AX + (R2 - 1) * AY + (R3 - 1) * AZ + 1;
     static constexpr int raw = e1max > e2max ? (e1max > M + 1 ? e1max : M + 1) : (e2max > M + 1 ? e2max : M + 1);
     static constexpr int LDS_ELEMS = (raw + 1) & ~1;  // float2 elements per frame slot, 16-byte multiple
     static constexpr int LDS_BYTES = LDS_ELEMS * TPB * 8;                          // dynamic: exchange buffers
@@ -234,6 +235,17 @@ struct Cfg {
 using Cfg512 = Cfg<512, 8, 8, 4, 32, 36, 4, 33, 1, 8, 1, 2>;   // (a 80-VGPR budget = 3 workgroups per CU measured no faster)
 using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, JSG_X_WPB1024, 1, 2, JSG_X_FPW1024, JSG_X_ABL>;
 using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, JSG_X_WPB2048, 1, JSG_X_WPS2048, JSG_X_FPW2048>;   // (6-, 8-, 12-wave workgroups: no faster)
+// 2048 points as TWO radix-32 stages with ONE exchange: 32 lanes per frame, 32 complex values per lane, two frames side by side
+// in a wavefront.  Against the three-stage plan (16*8*8, 64 lanes): the same butterfly count, but 40 % fewer LDS
+// instructions per frame (one exchange of 16 + 16 instead of two of 32 + 32), which is what capped C3 (VALU and LDS
+// each about half busy at two waves per SIMD).  One 8-wave workgroup per CU: 16 frames * 8.7 KB of exchange + 21 KB of tables.
+// It needs 210-256 VGPRs (two waves per SIMD, against four of the three-stage plan), so it is the plan of the launches whose
+// time goes into the transform (several channels mixed into one column: the dB epilogue and the column store run once per
+// column, not once per FFT); with one channel per column the epilogue of every round is exposed at two waves per SIMD and
+// the three-stage plan is 13-21 % faster, with two channels they tie (tools/abbench --cfg x2048, table in DESIGN.md).
+// The launcher picks by the number of channels mixed into a column (stft_launch_impl).
+using Cfg2048B = Cfg<2048, 32, 32, 1, 32, 34, 0, 0, 0, 8, 1, 1>;
+constexpr int k2048B_min_channels = 3;   // channels mixed into one column from which the two-stage plan is the faster one
 using Cfg4096 = Cfg<4096, 16, 8, 16, 128, 144, 1, 272, 17, 4, 1, 1>;    // two wavefronts per frame, two frames per workgroup
 using Cfg8192 = Cfg<8192, 16, 16, 16, 256, 272, 1, 272, 17, 4, 0, 1>;   // four wavefronts per frame, one frame per workgroup
 // (frames of more than one wavefront exchange through the workgroup barrier, so every further frame in the workgroup joins
@@ -340,7 +352,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     const int sub = L <= 64 ? lane / L : 0;
     const int slot0 = L <= 64 ? wave * C::SUB * F : wave / C::WPF;   // wave-uniform part of the slot
     cf* const lds0 = reinterpret_cast<cf*>(smem_raw) + (slot0 + sub * F) * C::LDS_ELEMS;   // frame f: lds0 + f * LDS_ELEMS
-    const int tl = L <= 64 ? lane : ll;                           // index into a lane-table row
+    const int tl = ll;                                            // index into a lane-table row (TL = L entries)
     unsigned long long st0 = 0, st1 = 0, st2 = 0, stA = 0, stC = 0, stP = 0, rt0 = 0;
     if constexpr (C::ABL == 3) { st0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 
@@ -443,17 +455,22 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     };
 
     // per-lane LDS element offsets of the two exchanges
-    int e1r[U2], e2w[U2], e2r[U3];
+    constexpr bool TWO = C::TWO_STAGE;
+    int e1r[U2], e2w[TWO ? 1 : U2], e2r[TWO ? 1 : U3];
 #pragma unroll
     for (int v = 0; v < U2; ++v) {
         const int t2 = ll + L * v;
         e1r[v] = (t2 / R3) * C::S1 + (t2 % R3);
-        e2w[v] = (t2 / R3) * C::AX + (t2 % R3) * C::AZ;
+        if constexpr (!TWO) e2w[v] = (t2 / R3) * C::AX + (t2 % R3) * C::AZ;
     }
+    if constexpr (!TWO) {
 #pragma unroll
-    for (int w = 0; w < U3; ++w) {
-        const int t3 = ll + L * w;
-        e2r[w] = (t3 % R1) * C::AX + (t3 / R1) * C::AY;
+        for (int w = 0; w < U3; ++w) {
+            const int t3 = ll + L * w;
+            e2r[w] = (t3 % R1) * C::AX + (t3 / R1) * C::AY;
+        }
+    } else {
+        e2w[0] = e2r[0] = 0;
     }
 
     float acc[F][P];
@@ -539,8 +556,17 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         for (int f = 0; f < F; ++f)
 #pragma unroll
             for (int v = 0; v < U2; ++v) {
+                if constexpr (TWO) {   // R3 == 1: the R2 values of a lane are neighbours in its row (S1 even: 16-byte aligned)
 #pragma unroll
-                for (int n2 = 0; n2 < R2; ++n2) x[f][v * R2 + n2] = lds0[f * C::LDS_ELEMS + e1r[v] + n2 * R3];
+                    for (int n2 = 0; n2 < R2; n2 += 2) {
+                        const v4f q4 = *reinterpret_cast<const v4f*>(lds0 + f * C::LDS_ELEMS + e1r[v] + n2);
+                        x[f][v * R2 + n2] = cf{q4.x, q4.y};
+                        x[f][v * R2 + n2 + 1] = cf{q4.z, q4.w};
+                    }
+                } else {
+#pragma unroll
+                    for (int n2 = 0; n2 < R2; ++n2) x[f][v * R2 + n2] = lds0[f * C::LDS_ELEMS + e1r[v] + n2 * R3];
+                }
             }
         frame_sync();
         // ---- stage 2: radix-R2 over n2, twiddle W_M^{n3 (k1 + R1 k2)}, exchange 2 ----
@@ -553,17 +579,25 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                 for (int n2 = 0; n2 < R2; ++n2) t[f][n2] = x[f][v * R2 + n2];
                 dft<R2>(t[f]);
             }
+            if constexpr (TWO) {   // n3 = 0: the stage-2 twiddle is 1, and Z[ll + L k2] already sits in register k2 of lane ll
 #pragma unroll
-            for (int k2 = 0; k2 < R2; k2 += 2) {
-                cf w0, w1;
-                tab2(C::TAB_TW2, v * R2 + k2, w0, w1);
+                for (int f = 0; f < F; ++f)
 #pragma unroll
-                for (int f = 0; f < F; ++f) {
-                    lds0[f * C::LDS_ELEMS + e2w[v] + k2 * C::AY] = cmul(t[f][k2], w0);
-                    lds0[f * C::LDS_ELEMS + e2w[v] + (k2 + 1) * C::AY] = cmul(t[f][k2 + 1], w1);
+                    for (int k2 = 0; k2 < R2; ++k2) x[f][v * R2 + k2] = t[f][k2];
+            } else {
+#pragma unroll
+                for (int k2 = 0; k2 < R2; k2 += 2) {
+                    cf w0, w1;
+                    tab2(C::TAB_TW2, v * R2 + k2, w0, w1);
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        lds0[f * C::LDS_ELEMS + e2w[v] + k2 * C::AY] = cmul(t[f][k2], w0);
+                        lds0[f * C::LDS_ELEMS + e2w[v] + (k2 + 1) * C::AY] = cmul(t[f][k2 + 1], w1);
+                    }
                 }
             }
         }
+        if constexpr (!TWO) {
         frame_sync();
         // ---- stage 3: radix-R3 over n3; Z[k], k = t3 + R1 R2 k3 ----
 #pragma unroll
@@ -585,6 +619,9 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
 #pragma unroll
                 for (int k3 = 0; k3 < R3; ++k3) x[f][w * R3 + k3] = t[k3];
             }
+        } else {
+            frame_sync();   // the post pass reuses the exchange buffer: keep its stores behind the exchange-1 loads
+        }
         {
             // ---- paired real-split post pass.  Bin k = ll + L*rho (rho = w + U3*k3).  A lane owns the pairs of its
             // lower registers rho < P/2: (k, M-k); Z[M-k] is the upper register P-1-rho of lane L-ll (lane 0: its own
@@ -663,23 +700,51 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                     for (int m = 0; m < P; ++m) acc[f][m] = to_db(acc[f][m]);
                     accNy[f] = to_db(accNy[f]);
                 }
+                if constexpr (L == 32) {
+                    // Two frames sit side by side in the wavefront (lanes 0-31 | 32-63), and register rho of a lane is bin
+                    // ll + 32 rho of ITS frame: stored as they lie, one instruction would write two 128-byte runs, in columns
+                    // whose starts are not 128-byte aligned.  v_permlane32_swap trades the upper half of register rho
+                    // (rho even) against the lower half of register rho + 1: afterwards register rho holds bins
+                    // 32 rho + lane of the lower frame over all 64 lanes and register rho + 1 the same bins of the upper
+                    // frame -- 256 contiguous bytes per store instruction, as in the 64-lane plans.
+#pragma unroll
+                    for (int m = 0; m < P; m += 2) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[f][m]), __float_as_uint(acc[f][m + 1]), false, false);
+                        acc[f][m] = __uint_as_float(sw[0]);
+                        acc[f][m + 1] = __uint_as_float(sw[1]);
+                    }
+                }
+                // column of the frame whose bins register rho holds after the swap (L == 32), else this lane's own
+                const unsigned colA = L == 32 ? (unsigned)__builtin_amdgcn_readlane((int)col, 0) : col;
+                const unsigned colB = L == 32 ? (unsigned)__builtin_amdgcn_readlane((int)col, 32) : col;
+                constexpr int LW = L == 32 ? 64 : L;         // lanes that share one store instruction's run
+                const int lw = L == 32 ? lane : ll;
                 if constexpr (OUTK == 1) {
                     // palette index of every bin; 64 consecutive bytes of the index column per store instruction
+                    unsigned char* icA = a.idx + (long long)colA * a.idx_pitch;
+                    unsigned char* icB = a.idx + (long long)colB * a.idx_pitch;
                     unsigned char* ic = a.idx + (long long)col * a.idx_pitch;
 #pragma unroll
                     for (int rho = 0; rho < P / 2; ++rho) {
-                        ic[ll + L * rho] = (unsigned char)color_index(acc[f][rho], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
-                        ic[M - (ll + L * rho)] = (unsigned char)color_index(acc[f][P / 2 + rho], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
+                        unsigned char* d = (L == 32 && (rho & 1)) ? icB : icA;
+                        const int k = lw + LW * (L == 32 ? rho / 2 : rho);
+                        d[k] = (unsigned char)color_index(acc[f][rho], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
+                        d[M - k] = (unsigned char)color_index(acc[f][P / 2 + rho], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
                     }
                     if (L <= 64 || ll == 0) ic[M / 2] = (unsigned char)color_index(accNy[f], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
                 } else if (C::ABL == 2 ? (acc[f][0] == 12345.678f) : true) {
                     // non-temporal dword stores, 256 contiguous bytes of the column per instruction (streaming the columns out
                     // instead of leaving them dirty in L2 removed the end-of-kernel write-back)
-                    float* dst = a.out + (long long)col * a.out_pitch + (a.per_channel ? (long long)c0 * a.out_cpitch : 0ll);
+                    const long long cofs = a.per_channel ? (long long)c0 * a.out_cpitch : 0ll;
+                    float* dstA = a.out + (long long)colA * a.out_pitch + cofs;
+                    float* dstB = a.out + (long long)colB * a.out_pitch + cofs;
+                    float* dst = a.out + (long long)col * a.out_pitch + cofs;
 #pragma unroll
                     for (int rho = 0; rho < P / 2; ++rho) {
-                        __builtin_nontemporal_store(acc[f][rho], &dst[ll + L * rho]);
-                        __builtin_nontemporal_store(acc[f][P / 2 + rho], &dst[M - (ll + L * rho)]);
+                        float* d = (L == 32 && (rho & 1)) ? dstB : dstA;
+                        const int k = lw + LW * (L == 32 ? rho / 2 : rho);
+                        __builtin_nontemporal_store(acc[f][rho], &d[k]);
+                        __builtin_nontemporal_store(acc[f][P / 2 + rho], &d[M - k]);
                     }
                     if (L <= 64 || ll == 0) __builtin_nontemporal_store(accNy[f], &dst[M / 2]);   // L <= 64: uniform over the frame's lanes
                 }
@@ -826,7 +891,7 @@ static void fill_tables(std::vector<float2>& t, const float* window, double amp)
             const double a2 = 0.5 * amp;   // the paired post pass expects Z/2
             t[C::TAB_WIN + C::tab_idx(m, e)] = make_float2(float(double(window[2 * n]) * a2), float(double(window[2 * n + 1]) * a2));
         }
-        for (int v = 0; v < C::U2; ++v)
+        for (int v = 0; v < (C::TWO_STAGE ? 0 : C::U2); ++v)
             for (int k2 = 0; k2 < R2; ++k2) {
                 const int t2 = ll + L * v, k1 = t2 / R3, n3 = t2 % R3;
                 const double ang = -two_pi * double((long long)n3 * (k1 + R1 * k2) % M) / double(M);
@@ -881,6 +946,7 @@ struct jsg_plan {
     int device = -1;
     float2* d_tab = nullptr;
     size_t tab_elems = 0;
+    float2* d_tab_b = nullptr;   // 2048 points: lane tables of the two-stage plan (Cfg2048B), behind d_tab in the same allocation
 };
 
 static unsigned long long* g_dev_stamps = nullptr;   // development builds: stamp buffer of the ABL == 3 variants
@@ -976,11 +1042,20 @@ int jsg_plan_create(jsg_plan** out, int n, const float* window, float power_scal
     *out = nullptr;
     if (!(power_scale > 0.f)) return jsg_fail(JSG_ERR_INVALID, "jsg_plan_create: power_scale must be > 0");
     std::vector<float2> t;
+    size_t tab_b_at = 0;
     const double amp = std::sqrt(double(power_scale));   // |FFT(a w x)|^2 = a^2 |FFT(w x)|^2
     switch (n) {
         case 512: fill_tables<Cfg512>(t, window, amp); break;
         case 1024: fill_tables<Cfg1024>(t, window, amp); break;
-        case 2048: fill_tables<Cfg2048>(t, window, amp); break;
+        case 2048: {   // both 2048-point plans (the launcher picks per launch); the second table set starts 256-byte aligned
+            fill_tables<Cfg2048>(t, window, amp);
+            std::vector<float2> tb;
+            fill_tables<Cfg2048B>(tb, window, amp);
+            t.resize((t.size() + 31) / 32 * 32, make_float2(0.f, 0.f));
+            tab_b_at = t.size();
+            t.insert(t.end(), tb.begin(), tb.end());
+            break;
+        }
         case 4096: fill_tables<Cfg4096>(t, window, amp); break;
         case 8192: fill_tables<Cfg8192>(t, window, amp); break;
         default:
@@ -1008,6 +1083,7 @@ int jsg_plan_create(jsg_plan** out, int n, const float* window, float power_scal
         delete p;
         return jsg_fail_hip(err, "jsg_plan_create");
     }
+    if (tab_b_at) p->d_tab_b = p->d_tab + tab_b_at;
     *out = p;
     return JSG_OK;
 }
@@ -1121,11 +1197,20 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     if (mixop == 0 && (ka.per_channel || ka.c_end - ka.c_begin == 1) && ka.scale == 1.0f && !ka.exact_div) mixop = 3;
     if (io && (ka.per_channel || (mixop != 0 && mixop != 3)))
         return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_image_launch: AbsMean / Sum / Left / Right mixes only");
+    // 2048 points: the two-stage plan where several channels are mixed into one column, else the three-stage plan (see
+    // Cfg2048B).  The choice depends on the launch geometry only, so the shards / sub-launches of one stream agree bit for bit.
+    bool plan_b = false;
+    if (plan->n == 2048) {
+        static const int forced = [] { const char* e = getenv("JSG_2048_PLAN"); return e ? atoi(e) : 0; }();   // development A/B: 2 | 3
+        const int nc = ka.per_channel ? 1 : ka.c_end - ka.c_begin;
+        plan_b = forced == 2 || (forced != 3 && nc >= k2048B_min_channels);
+        if (plan_b) ka.tab = plan->d_tab_b;
+    }
     int tpb = 0;
     switch (plan->n) {
         case 512: tpb = Cfg512::TPB; break;
         case 1024: tpb = Cfg1024::TPB; break;
-        case 2048: tpb = Cfg2048::TPB; break;
+        case 2048: tpb = plan_b ? Cfg2048B::TPB : Cfg2048::TPB; break;
         case 4096: tpb = Cfg4096::TPB; break;
         case 8192: tpb = Cfg8192::TPB; break;
     }
@@ -1150,7 +1235,7 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     switch (plan->n) {
         case 512: err = launch_stft<Cfg512>(ka, mixop, grid, s); break;
         case 1024: err = launch_stft<Cfg1024>(ka, mixop, grid, s); break;
-        case 2048: err = launch_stft<Cfg2048>(ka, mixop, grid, s); break;
+        case 2048: err = plan_b ? launch_stft<Cfg2048B>(ka, mixop, grid, s) : launch_stft<Cfg2048>(ka, mixop, grid, s); break;
         case 4096: err = launch_stft<Cfg4096>(ka, mixop, grid, s); break;
         case 8192: err = launch_stft<Cfg8192>(ka, mixop, grid, s); break;
     }

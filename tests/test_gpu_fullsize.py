@@ -219,12 +219,12 @@ def test_fused_image_every_plan(jsg, oracle, torch_cuda, n, channels, mix, lo, h
         jsg.stft_image(plan, d_in, hop, F, d_lut, lo, hi, fused, scratch, feedblocks=4, mix_mode=1)
 
 
-@pytest.mark.parametrize("n,F", [(4096, 9000), (8192, 5000), (2048, 20000), (512, 40000)])
-def test_persistent_loop_of_every_plan(jsg, oracle, torch_cuda, n, F):
+@pytest.mark.parametrize("n,F,C", [(4096, 9000, 2), (8192, 5000, 2), (2048, 20000, 2), (2048, 40001, 4), (512, 40000, 2), (512, 40001, 1)])
+def test_persistent_loop_of_every_plan(jsg, oracle, torch_cuda, n, F, C):
     """Launches large enough that every workgroup loops over several frames (iters > 1), incl. the plans whose frames
     span 2 / 4 wavefronts (workgroup barriers inside the loop): spot checks + batching invariance."""
     torch = torch_cuda
-    hop, C = 256, 2
+    hop = 256
     win = oracle.window(oracle.WIN_HANN, n)
     plan = jsg.Plan(n, win)
     d_in = _stream(torch, C, (F - 1) * hop + n, seed=n)

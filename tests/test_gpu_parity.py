@@ -59,6 +59,11 @@ CASES = [
     (1024, 1, 5, 0, 1),
     (1024, 1, 64, 0, 1),     # the full 64-channel mix of configs[3] on one GPU
     (1024, 0, 2, 0, 1),      # perc100: no overlap
+    # 2048 points with three or more channels mixed into a column: the two-stage plan
+    (2048, 1, 4, 1, 0),      # Max, Rect
+    (2048, 2, 5, 2, 2),      # Min, Hamming
+    (2048, 0, 3, 0, 3),      # AbsMean over three channels (IEEE division), no overlap
+    (2048, 3, 4, 0, 1),      # perc10: odd hop 205
 ]
 
 
@@ -237,6 +242,64 @@ def test_ragged_frame_counts(jsg, oracle, torch_cuda, n, frames):
     fr = (x[:, idx] * win[None, None, :]).astype(np.float32)
     pw = oracle.mix_channels(oracle.power_spectrum_f64(fr).astype(np.float32), oracle.MIX_ABSMEAN)
     assert_db_close(got[:frames, :H], oracle.to_db(pw), pw.astype(np.float64), f"n={n} frames={frames}")
+
+
+@pytest.mark.parametrize("n,channels", [(2048, 4), (512, 2), (512, 1)])
+@pytest.mark.parametrize("frames", [1, 2, 5, 16, 33])
+def test_ragged_frame_counts_two_frames_per_wavefront(jsg, oracle, torch_cuda, n, channels, frames):
+    """The 32-lane plans (512 points; 2048 points with >= 3 channels) put two frames into one wavefront and trade
+    register halves before the column store: odd frame counts (the upper frame of the last wavefront is a duplicate of
+    the lower one) and a ring whose wrap falls between the two frames of a wavefront."""
+    torch = torch_cuda
+    hop = n // 4
+    x = oracle.synth_audio(channels, (frames - 1) * hop + n, seed=frames + n, kind="noise")
+    win = oracle.window(oracle.WIN_HANN, n)
+    plan = jsg.Plan(n, win)
+    H = n // 2 + 1
+    W = frames + 2
+    pos = W - 1                                                      # frame 0 -> last column, frame 1 -> column 0
+    d_out = torch.full((W, H + 5), 7.0, device="cuda")
+    jsg.stft_db(plan, torch.from_numpy(x).cuda(), hop, frames, d_out, feedblocks=4, ring_pos=pos)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    cols = (pos + np.arange(frames)) % W
+    untouched = np.setdiff1d(np.arange(W), cols)
+    assert (got[untouched] == 7.0).all() and (got[:, H:] == 7.0).all(), "stored outside the requested columns"
+    idx = (np.arange(frames) * hop)[:, None] + np.arange(n)[None, :]
+    fr = (x[:, idx] * win[None, None, :]).astype(np.float32)
+    pw = oracle.mix_channels(oracle.power_spectrum_f64(fr).astype(np.float32), oracle.MIX_ABSMEAN)
+    assert_db_close(got[cols, :H], oracle.to_db(pw), pw.astype(np.float64), f"n={n} C={channels} frames={frames}")
+
+
+def test_2048_point_plans_agree(jsg, oracle, torch_cuda):
+    """The launcher uses the three-stage 2048-point plan for one or two channels per column and the two-stage plan from
+    three channels on.  Linear power of both against the float64 DFT; and the same stream through both (channels
+    duplicated so that the mixes are equal) stays within the float32 bound of one another."""
+    torch = torch_cuda
+    n, hop, K = 2048, 512, 10
+    x = oracle.synth_audio(4, K * n, seed=11, kind="mix")
+    win = oracle.window(oracle.WIN_BLACKMANHARRIS, n)
+    plan = jsg.Plan(n, win)
+    F = (K - 1) * 4 + 1
+    H = n // 2 + 1
+    idx = (np.arange(F) * hop)[:, None] + np.arange(n)[None, :]
+    fr = (x[:, idx] * win[None, None, :]).astype(np.float32)
+    p64 = oracle.power_spectrum_f64(fr)                              # [C][F][H]
+    for C in (1, 2, 3, 4):
+        d_out = torch.empty((F, H), device="cuda")
+        jsg.stft_db(plan, torch.from_numpy(x[:C].copy()).cuda(), hop, F, d_out, mix_mode=jsg.capi.MIX_SUM, linear_out=True)
+        torch.cuda.synchronize()
+        worst = assert_power_close(d_out.cpu().numpy(), p64[:C].sum(axis=0), f"2048 points, {C} channels summed")
+        assert worst < 1e-5, (C, worst)
+    # one channel four times: the AbsMean of four equal channels is the channel itself up to one rounding of the sum
+    one = torch.from_numpy(x[:1].copy()).cuda()
+    d1 = torch.empty((F, H), device="cuda"); d4 = torch.empty((F, H), device="cuda")
+    jsg.stft_db(plan, one, hop, F, d1, linear_out=True)
+    jsg.stft_db(plan, one.repeat(4, 1).contiguous(), hop, F, d4, linear_out=True)
+    torch.cuda.synchronize()
+    a, b = d1.cpu().numpy().astype(np.float64), d4.cpu().numpy().astype(np.float64)
+    peak = p64[0].max(axis=-1, keepdims=True)
+    assert (np.abs(a - b) <= 2 * (1e-5 * p64[0] + 1e-6 * peak)).all()
 
 
 def test_empty_inputs_and_bad_geometry(jsg, oracle, torch_cuda):

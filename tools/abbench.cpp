@@ -111,6 +111,23 @@ static const Config kConfigs[] = {
     {"sizes", 4096, 1024, 1, 16384, JSG_MIX_ABSMEAN, false},
     {"sizes", 8192, 4096, 1, 8192, JSG_MIX_ABSMEAN, false},
     {"sizes", 8192, 2048, 1, 8192, JSG_MIX_ABSMEAN, false},
+    // --cfg x2048: 32768 FFTs of 2048 points at every overlap / channel count (which of the two 2048-point plans, JSG_2048_PLAN)
+    {"x2048", 2048, 1024, 1, 32768, JSG_MIX_ABSMEAN, false},
+    {"x2048", 2048, 512, 1, 32768, JSG_MIX_ABSMEAN, false},
+    {"x2048", 2048, 256, 1, 32768, JSG_MIX_ABSMEAN, false},
+    {"x2048", 2048, 128, 1, 32768, JSG_MIX_ABSMEAN, false},
+    {"x2048", 2048, 1024, 2, 16384, JSG_MIX_ABSMEAN, false},
+    {"x2048", 2048, 512, 2, 16384, JSG_MIX_ABSMEAN, false},
+    {"x2048", 2048, 256, 2, 16384, JSG_MIX_ABSMEAN, false},
+    {"x2048", 2048, 128, 2, 16384, JSG_MIX_ABSMEAN, false},
+    {"x2048", 2048, 1024, 4, 8192, JSG_MIX_ABSMEAN, false},
+    {"x2048", 2048, 512, 4, 8192, JSG_MIX_ABSMEAN, false},
+    {"x2048", 2048, 256, 4, 8192, JSG_MIX_ABSMEAN, false},
+    {"x2048", 2048, 128, 4, 8192, JSG_MIX_ABSMEAN, false},
+    {"x2048", 2048, 1024, 8, 4096, JSG_MIX_ABSMEAN, false},
+    {"x2048", 2048, 512, 8, 4096, JSG_MIX_ABSMEAN, false},
+    {"x2048", 2048, 256, 8, 4096, JSG_MIX_ABSMEAN, false},
+    {"x2048", 2048, 128, 8, 4096, JSG_MIX_ABSMEAN, false},
     // --cfg c4sweep: the C4 shard (8 channels per GPU, per-channel columns) at other launch sizes
     {"c4sweep", 1024, 512, 8, 1024, JSG_MIX_PER_CHANNEL, false},
     {"c4sweep", 1024, 512, 8, 16384, JSG_MIX_PER_CHANNEL, false},
