@@ -246,7 +246,16 @@ using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, JSG_X_WPB2048, 1, JSG_X_W
 // The launcher picks by the number of channels mixed into a column (stft_launch_impl).
 using Cfg2048B = Cfg<2048, 32, 32, 1, 32, 34, 0, 0, 0, 8, 1, 1>;
 constexpr int k2048B_min_channels = 3;   // channels mixed into one column from which the two-stage plan is the faster one
-using Cfg4096 = Cfg<4096, 16, 8, 16, 128, 144, 1, 272, 17, 4, 1, 1>;    // two wavefronts per frame, two frames per workgroup
+#ifndef JSG_X_WPB4096
+#define JSG_X_WPB4096 4
+#endif
+#ifndef JSG_X_WPS4096
+#define JSG_X_WPS4096 1
+#endif
+#ifndef JSG_X_TLOC4096
+#define JSG_X_TLOC4096 1
+#endif
+using Cfg4096 = Cfg<4096, 16, 8, 16, 128, 144, 1, 272, 17, JSG_X_WPB4096, JSG_X_TLOC4096, JSG_X_WPS4096>;    // two wavefronts per frame, two frames per workgroup
 using Cfg8192 = Cfg<8192, 16, 16, 16, 256, 272, 1, 272, 17, 4, 0, 1>;   // four wavefronts per frame, one frame per workgroup
 // (frames of more than one wavefront exchange through the workgroup barrier, so every further frame in the workgroup joins
 // five barriers per FFT: 8-wave workgroups were 9-15 % slower, 12-wave ones 30 %)

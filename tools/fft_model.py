@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Design model of the wave-per-frame FFT used by jadespectrogram_amd/csrc/jsg_stft.hip  (DEV TOOL).
+"""Design model of the wave-per-frame FFT used by jadespectrogram_amd/csrc/jsg_kernels.hip  (DEV TOOL).
 
 One wavefront (64 lanes) transforms one real frame of N samples as an M = N/2 point complex FFT with
 P = M/64 complex values per lane, in three register-resident stages of radix R1, R2, R3 (R1*R2*R3 = M)
-separated by two wave-private LDS exchanges, followed by the real-split post pass.
+separated by two wave-private LDS exchanges, followed by the real-split post pass.  R3 = 1 is the two-stage plan
+(Cfg2048B): one exchange, read back as 16-byte pairs, and the second radix stage leaves bin ll + L*k2 in register k2.
 
 This script (a) checks the index algebra numerically against numpy.fft, (b) counts LDS bank conflicts
 of a layout under the gfx950 banking rules (MI355X_MICROARCH.md "LDS"), and (c) searches paddings.
@@ -35,7 +36,10 @@ class Plan:
         self.B = B if B is not None else R3 + 1
         self.A = A if A is not None else R2 * self.B
         self.Z = Z
-        self.lds_elems = max((R1 - 1) * self.S1 + self.M // R1, (R1 - 1) * self.A + (R2 - 1) * self.B + (R3 - 1) * Z + 1, self.M + 1)
+        self.two_stage = R3 == 1
+        e2 = 0 if self.two_stage else (R1 - 1) * self.A + (R2 - 1) * self.B + (R3 - 1) * Z + 1
+        self.lds_elems = max((R1 - 1) * self.S1 + self.M // R1, e2, self.M + 1)
+        self.lds_elems += self.lds_elems & 1   # 16-byte multiple, as Cfg::LDS_ELEMS
         Plan.HALF_OFFSET = self.lds_elems
 
     # ---- addresses (in complex-element units) -------------------------------------------------
@@ -83,7 +87,7 @@ class Plan:
                 for k1 in range(R1):
                     lds[self.a1(k1, lane + LANES * u)] = y[k1] * self.tw1(u, k1, lane)
         # stage 2
-        nxt = np.zeros_like(lds)
+        nxt = {} if self.two_stage else np.zeros_like(lds)   # two-stage plan: the results stay in registers (no layout)
         for lane in range(LANES):
             for v in range(U2):
                 t2 = lane + LANES * v
@@ -91,7 +95,7 @@ class Plan:
                 x = np.array([lds[self.a1(k1, n2 * R3 + n3)] for n2 in range(R2)])
                 y = np.fft.fft(x)
                 for k2 in range(R2):
-                    nxt[self.a2(k1, k2, n3)] = y[k2] * self.tw2(v, k2, lane)
+                    nxt[(k1, k2) if self.two_stage else self.a2(k1, k2, n3)] = y[k2] * self.tw2(v, k2, lane)
         lds = nxt
         # stage 3
         Z = np.zeros(M + 1, dtype=np.complex128)
@@ -99,7 +103,7 @@ class Plan:
             for w in range(U3):
                 t3 = lane + LANES * w
                 k1, k2 = t3 % R1, t3 // R1
-                x = np.array([lds[self.a2(k1, k2, n3)] for n3 in range(R3)])
+                x = np.array([lds[(k1, k2) if self.two_stage else self.a2(k1, k2, n3)] for n3 in range(R3)])
                 y = np.fft.fft(x)
                 for k3 in range(R3):
                     Z[t3 + R1 * R2 * k3] = y[k3]
@@ -184,11 +188,19 @@ class Plan:
             for k1 in range(R1):
                 acc("x1 write", [self.a1(k1, l + LANES * u) for l in range(LANES)], "w")
         for v in range(U2):
+            if self.two_stage:   # the R2 values of a lane are neighbours in its row: 16-byte reads of pairs (n2, n2 + 1)
+                for n2 in range(0, R2, 2):
+                    addrs = [self.a1(l + LANES * v, n2) for l in range(LANES)]
+                    addrs = addrs + [a + Plan.HALF_OFFSET for a in addrs] if len(addrs) == 32 else addrs
+                    c, ideal = self._cycles_b128(addrs)
+                    a = tot.setdefault("x1 read (16 B)", [0, 0])
+                    a[0] += c; a[1] += ideal
+                continue
             for n2 in range(R2):
                 acc("x1 read", [self.a1((l + LANES * v) // R3, n2 * R3 + (l + LANES * v) % R3) for l in range(LANES)], "r")
             for k2 in range(R2):
                 acc("x2 write", [self.a2((l + LANES * v) // R3, k2, (l + LANES * v) % R3) for l in range(LANES)], "w")
-        for w in range(U3):
+        for w in range(0 if self.two_stage else U3):
             for n3 in range(R3):
                 acc("x2 read", [self.a2((l + LANES * w) % R1, (l + LANES * w) // R1, n3) for l in range(LANES)], "r")
         if verbose:
@@ -199,8 +211,11 @@ class Plan:
     def check_injective(self):
         R1, R2, R3 = self.R
         s1 = {self.a1(k1, t1) for k1 in range(R1) for t1 in range(self.M // R1)}
+        assert max(s1) < self.lds_elems
+        if self.two_stage:
+            return len(s1) == self.M
         s2 = {self.a2(k1, k2, n3) for k1 in range(R1) for k2 in range(R2) for n3 in range(R3)}
-        assert max(s2) < self.lds_elems and max(s1) < self.lds_elems
+        assert max(s2) < self.lds_elems
         return len(s1) == self.M and len(s2) == self.M
 
 
@@ -224,11 +239,13 @@ def search(N, R1, R2, R3, L=64):
 
 # N: (R1, R2, R3, lanes per frame, S1, AX, AY, AZ) -- the plans compiled into jsg_kernels.hip
 CONFIGS = {512: (8, 8, 4, 32, 36, 4, 33, 1), 1024: (8, 8, 8, 64, 72, 9, 72, 2), 2048: (16, 8, 8, 64, 72, 65, 16, 2),
+           "2048B": (32, 32, 1, 32, 34, 0, 0, 0),   # two-stage plan of the launches that mix >= 3 channels per column
            4096: (16, 8, 16, 128, 144, 1, 272, 17), 8192: (16, 16, 16, 256, 272, 1, 272, 17)}
 
 if __name__ == "__main__":
     rng = np.random.default_rng(0)
     for N, cfg in CONFIGS.items():
+        N = int(str(N).rstrip("B"))
         R1, R2, R3, L, S1, AX, AY, AZ = cfg
         if len(sys.argv) > 1 and sys.argv[1] == "search":
             print(N, (R1, R2, R3), "best (cycles, lds_elems), (S1,A,B), ideal:", search(N, R1, R2, R3, L))
