@@ -302,6 +302,46 @@ def test_2048_point_plans_agree(jsg, oracle, torch_cuda):
     assert (np.abs(a - b) <= 2 * (1e-5 * p64[0] + 1e-6 * peak)).all()
 
 
+def _random_geometries(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        n = int(rng.choice([512, 1024, 2048, 2048, 4096, 8192]))
+        channels = int(rng.integers(1, 10))
+        mix = int(rng.choice([0, 0, 1, 2, 3, 4]))
+        if mix == 4 and channels < 2:
+            mix = 3
+        feedblocks = int(rng.choice([1, 2, 4, 8, 10]))
+        hop = n // feedblocks if feedblocks != 10 else [51, 102, 205, 410, 819][[512, 1024, 2048, 4096, 8192].index(n)]
+        frames = int(rng.integers(1, 70))
+        extra = int(rng.integers(0, 4))
+        out.append((n, channels, mix, feedblocks, hop, frames, extra))
+    return out
+
+
+@pytest.mark.parametrize("n,channels,mix,feedblocks,hop,frames,extra", _random_geometries(48, 20260))
+def test_seeded_random_geometries(jsg, oracle, torch_cuda, n, channels, mix, feedblocks, hop, frames, extra):
+    """Seeded sweep over plan x channel count x mix x hop pattern x frame count x ring position (every kernel
+    instantiation, both 2048-point plans, the perc10 pattern of Spectrogram.cpp:50-55,216) against the float64 DFT."""
+    torch = torch_cuda
+    starts = np.array([(j // feedblocks) * n + (j % feedblocks) * hop for j in range(frames)])
+    x = oracle.synth_audio(channels, int(starts[-1]) + n, seed=n + frames, kind="noise" if frames % 2 else "mix")
+    win = oracle.window((frames + channels) % 6, n)
+    plan = jsg.Plan(n, win)
+    H = n // 2 + 1
+    W = frames + extra
+    pos = (W - 1) if extra else 0
+    d_out = torch.full((W, H + 2), 7.0, device="cuda")
+    jsg.stft_db(plan, torch.from_numpy(x).cuda(), hop, frames, d_out, feedblocks=feedblocks, mix_mode=mix, ring_pos=pos)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    cols = (pos + np.arange(frames)) % W
+    assert (got[np.setdiff1d(np.arange(W), cols)] == 7.0).all() and (got[:, H:] == 7.0).all(), "stored outside the requested columns"
+    fr = (x[:, starts[:, None] + np.arange(n)[None, :]] * win[None, None, :]).astype(np.float32)
+    pw = oracle.mix_channels(oracle.power_spectrum_f64(fr).astype(np.float32), mix)
+    assert_db_close(got[cols, :H], oracle.to_db(pw), pw.astype(np.float64), f"n={n} C={channels} mix={mix} fb={feedblocks} hop={hop} F={frames}")
+
+
 def test_empty_inputs_and_bad_geometry(jsg, oracle, torch_cuda):
     torch = torch_cuda
     n = 1024
