@@ -13,10 +13,13 @@ result does not depend on how many steps the driver asks for:
       Hann) = 4 194 304 frames.  The launches of a step are independent batches; they are issued by ONE C call
       (jsg_stft_db_launch_many_threads) round-robin over 8 HIP streams, so the ramp-up and drain of one launch overlap
       the others.  `value` = frames of all ranks / wall time of the K steps.
-  c3 (configs[2]): one step = 64 launches x 4096 columns of 8-channel 2048-point frames, 75 % overlap, AbsMean mix.
+  c3 (configs[2]): one step = 64 launches x 4096 columns of 8-channel 2048-point frames, 75 % overlap, AbsMean mix,
+      issued like c2 over 2 streams.
   c5 (configs[4]): one step = 128 launches x 1875 columns, stereo 96 kHz, 4096-point FFT, 87.5 % overlap, fused
-      STFT -> palette index -> ARGB image (jsg_stft_image_launch).
-  c3 / c5 are replayed in order from a hipGraph (their launches fill the GPU on their own).
+      STFT -> palette index -> ARGB image (jsg_stft_image_launch).  The images of a step are independent; they are
+      replayed from two hipGraphs on two streams (image i on stream i % 2), so the colour kernel of one image runs beside
+      the STFT kernel of the next.
+  `--streams 1` times every configuration in order on one stream (that is also what `roofline` reports, see below).
 
 The batches rotate over enough distinct buffers to exceed the 256 MiB Infinity Cache, so every launch streams from
 and to HBM.  Before the W warm-up steps the same launches run for about 0.3 s so that the clocks have settled.
@@ -49,10 +52,10 @@ CONFIGS = {
     "c2": dict(n=1024, hop=512, channels=1, frames=4096, fs=48000.0, colour=False, launches_per_step=1024, streams=8,
                metric="STFT frames/sec (1024-pt, 50% hop)", unit="frames/s",
                workload="configs[1]: mono 48 kHz, 1024-pt FFT, 512 hop, Hann, 4096 frames/launch, input + dB ring resident in HBM"),
-    "c3": dict(n=2048, hop=512, channels=8, frames=4096, fs=48000.0, colour=False, launches_per_step=64, streams=1,
+    "c3": dict(n=2048, hop=512, channels=8, frames=4096, fs=48000.0, colour=False, launches_per_step=64, streams=2,
                metric="STFT frames/sec (2048-pt, 75% overlap, 8 channels mixed to one column)", unit="frames/s",
                workload="configs[2]: 8-channel 48 kHz, 2048-pt FFT, 512 hop (75 % overlap), Hann, AbsMean mix, 4096 columns/launch"),
-    "c5": dict(n=4096, hop=512, channels=2, frames=1875, fs=96000.0, colour=True, launches_per_step=128, streams=1,
+    "c5": dict(n=4096, hop=512, channels=2, frames=1875, fs=96000.0, colour=True, launches_per_step=128, streams=2,
                metric="STFT->ARGB columns/sec (4096-pt, 87.5% overlap, stereo 96 kHz)", unit="columns/s",
                workload="configs[4]: stereo 96 kHz, 4096-pt FFT, 512 hop (87.5 % overlap), AbsMean, Jade LUT -50..50 dB -> ARGB image, "
                         "1875 columns (10 s) per launch, fused STFT -> palette index -> ARGB"),
@@ -207,7 +210,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--launches-per-step", type=int, default=0, help="launches in one step (default: the configuration's)")
     ap.add_argument("--nbuf", type=int, default=0, help="distinct batches rotated through (default: enough for > 256 MiB)")
-    ap.add_argument("--streams", type=int, default=0, help="HIP streams of the timed region (default: 8 for c2, 1 otherwise)")
+    ap.add_argument("--streams", type=int, default=0, help="HIP streams of the timed region (default: 8 for c2, 2 for c3 / c5; 1 = in order)")
     ap.add_argument("--issue-threads", type=int, default=2, help="host threads issuing the launches of a step (c2, streams > 1)")
     ap.add_argument("--blocks-per-cu", type=int, default=1, help="workgroups per CU of each launch when launches overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -360,7 +363,26 @@ def main():
                 with torch.cuda.stream(one):
                     graph.replay()
 
-        if n_streams > 1:
+        if n_streams > 1 and c["colour"]:
+            # ---- independent images on n_streams streams: one hipGraph per stream (image i goes to stream i % n_streams, so a
+            #      batch's scratch and image are always rewritten in order), replayed together: the colour kernel of one image
+            #      runs beside the STFT kernel of the next ----
+            streams = [torch.cuda.Stream() for _ in range(n_streams)]
+            graphs = []
+            for si, st in enumerate(streams):
+                gph = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(st):
+                    with torch.cuda.graph(gph, stream=st):
+                        for i in range(si, lps, n_streams):
+                            launch(i % nbuf, st.cuda_stream)
+                graphs.append(gph)
+            torch.cuda.synchronize()
+
+            def run_step():
+                for st, gph in zip(streams, graphs):
+                    with torch.cuda.stream(st):
+                        gph.replay()
+        elif n_streams > 1:
             # ---- the overlapped group: lps independent launches from ONE C call over n_streams streams ----
             arr = (capi.StftArgs * lps)()
             for i in range(lps):
@@ -477,7 +499,7 @@ def main():
                    "step": f"{lps} launches x {F} {'columns' if c['colour'] or C > 1 else 'frames'} = {lps * units_per_launch} {c['unit'].split('/')[0]} per step and GPU",
                    "launches_per_step": lps, "frames_per_launch": F * C, "columns_per_launch": F, "channels_per_gpu": C,
                    "distinct_batches": nbuf, "hip_streams_per_gpu": n_streams,
-                   "issue": ((("host-issued behind a gate kernel, in order and back to back on one stream (the gate is inside the timed region: this mode is for the tracer)" if args.gate else "host-issued, in order on one stream") if args.no_graph else "hipGraph replay, in order") if n_streams == 1 else f"one C call per step, {max(1, args.issue_threads)} host thread(s)"),
+                   "issue": ((("host-issued behind a gate kernel, in order and back to back on one stream (the gate is inside the timed region: this mode is for the tracer)" if args.gate else "host-issued, in order on one stream") if args.no_graph else "hipGraph replay, in order") if n_streams == 1 else (f"{n_streams} hipGraphs per step (independent images, one stream each), replayed together" if c["colour"] else f"one C call per step, {max(1, args.issue_threads)} host thread(s)")),
                    "prewarm_s": round(prewarm_s, 3),
                    "parallelism": f"{world} GPU(s), independent batches, no data-path collective"},
     }
@@ -507,7 +529,7 @@ def main():
             "algorithmic_bytes_per_launch": algo,
             "timed_region_achieved": conc, "timed_region_frac_of_8p0": conc / HBM_PEAK_GBS, "timed_region_frac_of_6p3": conc / HBM_ACHIEVABLE_GBS,
             "note": "achieved/frac: per-kernel view (in order, one stream); timed_region_*: algorithmic bytes of the K timed steps / their wall "
-                    "time (c2: launches overlapped on hip_streams_per_gpu streams)",
+                    "time (independent launches overlapped on hip_streams_per_gpu streams)",
             "memcpy_same_bytes_us": copy_us, "frac_of_memcpy_rate": (copy_us / inorder_us) if copy_us else None,
             "commit": commit,
         }
