@@ -8,7 +8,7 @@ import jadespectrogram_amd as jsg
 from jadespectrogram_amd import capi
 from jadespectrogram_amd.spectrogram import _stft_args
 lib = capi.lib()
-for n, frames, ch in ((512, 3001, 1), (1024, 4096, 1), (1024, 1000, 3), (2048, 2049, 2), (4096, 1025, 1), (8192, 513, 2)):
+for n, frames, ch in ((512, 3001, 1), (1024, 4096, 1), (1024, 1000, 3), (2048, 2049, 2), (2048, 2049, 5), (4096, 1025, 1), (8192, 513, 2)):
     hop = n // 4
     H = n // 2 + 1; pitch = (H + 31) // 32 * 32
     plan = jsg.Plan(n, jsg.window(2, n))
