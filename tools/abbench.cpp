@@ -100,6 +100,8 @@ static const Config kConfigs[] = {
     {"c5", 4096, 512, 2, 1875, JSG_MIX_ABSMEAN, true},     // configs[4]: stereo, 87.5 % overlap, 10 s ring -> ARGB
     {"big", 1024, 512, 1, 65536, JSG_MIX_ABSMEAN, false},  // asymptotic rate of the 1024-point plan
     {"c3big", 2048, 512, 8, 16384, JSG_MIX_ABSMEAN, false},
+    {"n512", 512, 256, 1, 131072, JSG_MIX_ABSMEAN, false},   // single plans (counter passes: tools/pmc_ab.sh r02_n512 n512 ...)
+    {"n8192", 8192, 4096, 1, 8192, JSG_MIX_ABSMEAN, false},
     // --cfg sizes: every plan at 50 % and 75 % overlap, mono, launches of 64 Mi samples' worth of frames
     {"sizes", 512, 256, 1, 131072, JSG_MIX_ABSMEAN, false},
     {"sizes", 512, 128, 1, 131072, JSG_MIX_ABSMEAN, false},
