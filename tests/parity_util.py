@@ -29,9 +29,13 @@ def assert_power_close(p_gpu, p_ref64, what=""):
     return float(np.max(err[strong] / p_ref64[strong])) if strong.any() else 0.0
 
 
-def assert_db_close(db_gpu, db_ref, p_ref64, what=""):
-    """db_ref: oracle dB (float32); p_ref64: the (mixed) linear power the oracle took the log of."""
-    peak = p_ref64.max(axis=-1, keepdims=True)
+def assert_db_close(db_gpu, db_ref, p_ref64, what="", peak=None):
+    """db_ref: oracle dB (float32); p_ref64: the (mixed) linear power the oracle took the log of.  peak: the frame peak the
+    FLOOR term refers to; default: the peak of the mixed column.  A selecting mix (Min, Max, Left, Right) picks single
+    channels' bins, whose float32 error scales with THAT channel's frame peak: such callers pass the largest per-channel
+    peak of the frame (Min over 8 noise channels otherwise shrinks the yardstick to the weakest channel's bins)."""
+    if peak is None:
+        peak = p_ref64.max(axis=-1, keepdims=True)
     r = REL + FLOOR * peak / (p_ref64 + LOG_FLOOR)
     tol = 10.0 * np.log10(1.0 + r) + DB_SLACK
     err = np.abs(db_gpu.astype(np.float64) - db_ref.astype(np.float64))

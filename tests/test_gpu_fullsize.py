@@ -1,5 +1,7 @@
 """BASELINE.json's full-size configurations: size-independent properties (Parseval, batching invariance, silence),
 plus spot checks of randomly chosen frames against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -241,3 +243,42 @@ def test_persistent_loop_of_every_plan(jsg, oracle, torch_cuda, n, F, C):
     assert torch.equal(d_a[:, :H], d_b[:, :H])
     frames = sorted(np.random.default_rng(n).choice(F, 6, replace=False).tolist()) + [0, F - 1]
     _spot_check(oracle, d_in, d_a[frames][:, :H].cpu().numpy(), n, hop, win, frames)
+
+
+def _random_images(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        n = int(rng.choice([512, 1024, 2048, 2048, 4096, 8192]))
+        channels = int(rng.integers(1, 7))
+        mix = int(rng.choice([0, 0, 3, 4]))
+        if mix == 4 and channels < 2:
+            mix = 3
+        fb = int(rng.choice([1, 2, 4, 8]))
+        frames = int(rng.integers(1, 200))
+        lo = float(rng.choice([-110.0, -80.0, -50.0, 0.0, 20.0]))
+        hi = float(rng.choice([-60.0, 0.0, 10.0, 50.0, 20.0]))
+        out.append((n, channels, mix, fb, frames, lo, hi, int(rng.integers(0, 7))))
+    return out
+
+
+@pytest.mark.parametrize("n,channels,mix,fb,frames,lo,hi,scheme",
+                         _random_images(int(os.environ.get("JSG_FUZZ_CASES", "24")), int(os.environ.get("JSG_FUZZ_SEED", "5"))))
+def test_seeded_random_fused_images(jsg, oracle, torch_cuda, n, channels, mix, fb, frames, lo, hi, scheme):
+    """Fused STFT -> index -> ARGB against the two-kernel path, bit for bit, over plans / channel counts / mixes / colour
+    ranges (swapped and degenerate ranges included) / ragged image widths."""
+    torch = torch_cuda
+    hop = n // fb
+    plan = jsg.Plan(n, oracle.window(oracle.WIN_HANN, n))
+    d_in = _stream(torch, channels, (frames - 1) * hop + n, seed=n + frames)
+    H = n // 2 + 1
+    d_db = torch.empty((frames, (H + 31) // 32 * 32), device="cuda")
+    d_lut = torch.from_numpy(jsg.colormap_lut(256, scheme)).cuda()
+    two = torch.zeros((H, frames), dtype=torch.int32, device="cuda")
+    jsg.stft_db(plan, d_in, hop, frames, d_db, feedblocks=fb, mix_mode=mix)
+    jsg.colormap(d_db, d_lut, lo, hi, d_argb=two, height=H)
+    fused = torch.zeros_like(two)
+    scratch = torch.zeros((frames, (H + 63) // 64 * 64), dtype=torch.uint8, device="cuda")
+    jsg.stft_image(plan, d_in, hop, frames, d_lut, lo, hi, fused, scratch, feedblocks=fb, mix_mode=mix)
+    torch.cuda.synchronize()
+    assert torch.equal(fused, two)
