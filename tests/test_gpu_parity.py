@@ -158,6 +158,53 @@ def test_block_by_block_stream_pause_and_getmem(jsg, oracle):
         e.close()
 
 
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("JSG_FUZZ_SCENARIOS", "10")))))
+def test_seeded_random_engine_scenarios(jsg, oracle, seed):
+    """Random walks over the engine's setter / process / pause / getMem surface, mirrored on the oracle engine: the column
+    counters and write positions must agree exactly after every getMem (every setter wipes the history like the
+    reference's buildmem), the ring contents within the coarse bound used above (fine tolerances: test_engine_db_columns)."""
+    rng = np.random.default_rng(1000 + seed)
+    C = int(rng.integers(1, 5))
+    s = jsg.Spectrogram(C); o = oracle.OracleSpectrogram(C)
+    n = int(rng.choice([512, 1024, 2048]))
+    s.setSamplerate(48000.0); o.set_samplerate(48000.0)
+    s.setmemoryTime_s(0.2); o.set_memory_time_s(0.2)
+    s.setFFTSize(n); o.set_fft_size(n)
+    x = oracle.synth_audio(C, 64 * 4096, seed=seed, kind="mix")
+    at = 0
+    for step in range(60):
+        ev = rng.choice(["block"] * 12 + ["getmem"] * 3 + ["pause", "feed", "window", "mix", "fft", "memtime"])
+        if ev == "block":
+            if at + n > x.shape[1]:
+                at = 0
+            blk = x[:, at:at + n]; at += n
+            assert s.processSynchronBlock(blk) == 0
+            o.process_synchron_block(blk)
+        elif ev == "pause":
+            p = bool(rng.integers(0, 2)); s.setPauseMode(p); o.set_pause_mode(p)
+        elif ev == "feed":
+            f = int(rng.integers(0, 4)); s.setfeed_percent(f); o.set_feed_percent(f)
+        elif ev == "window":
+            w = int(rng.integers(0, 6)); s.setWindow(w); o.set_window(w)
+        elif ev == "mix":
+            m = int(rng.integers(0, 5 if C > 1 else 4)); s.setMixMode(m); o.mode = m
+        elif ev == "fft":
+            n = int(rng.choice([512, 1024, 2048, 4096])); s.setFFTSize(n); o.set_fft_size(n)
+        elif ev == "memtime":
+            t = float(rng.choice([0.1, 0.2, 0.5])); s.setmemoryTime_s(t); o.set_memory_time_s(t)
+        if ev == "getmem" or step == 59:
+            W, H = s.getMemorySize(), s.getSpectrumSize()
+            assert (W, H, s.getFeedSamples()) == (o.memsize_blocks, o.freqsize, o.hop), (seed, step)
+            mg = np.zeros((W, H), np.float32); mo = np.zeros((W, H), np.float32)
+            assert s.getMem(mg) == o.get_mem(mo), (seed, step)
+            # this test is about the state machine: bins within 60 dB of their column's peak to 2e-3 dB, the weak rest
+            # (deep window side lobes, where two float32 FFTs differ visibly) only coarsely
+            d = np.abs(mg.astype(np.float64) - mo.astype(np.float64))
+            strong = mo > (mo.max(axis=1, keepdims=True) - 60.0)
+            assert d[strong].max() < 2e-3 and d.max() < 0.5, (seed, step, float(d[strong].max()), float(d.max()))
+    s.close()
+
+
 def test_silence_and_full_scale(jsg, oracle):
     n = 1024
     s = jsg.Spectrogram(1)
