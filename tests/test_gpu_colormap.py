@@ -175,6 +175,52 @@ def test_display_tile_updates_match_full_image(jsg, oracle):
     s.close()
 
 
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("JSG_FUZZ_SCENARIOS", "8")))))
+def test_seeded_random_display_walks(jsg, oracle, seed):
+    """Random GUI sessions: bursts of audio blocks (also more than a ring's worth), ticks, running <-> fixed display, colour
+    range / scheme changes, pause.  After every tick the incrementally maintained image must equal a full recolour of the
+    ring, bit for bit (reference Spectrogram.cpp:623-724: scroll + new columns, or fixed mode with its cursor; the
+    reference's incremental fixed mode paints the cursor 1 / 2 / 4 columns wide, its full recolour one column: mirrored)."""
+    rng = np.random.default_rng(500 + seed)
+    C = int(rng.integers(1, 3)); n = int(rng.choice([512, 1024, 2048]))
+    s = jsg.Spectrogram(C)
+    s.setSamplerate(48000.0); s.setmemoryTime_s(float(rng.choice([0.15, 0.3]))); s.setFFTSize(n); s.setfeed_percent(int(rng.integers(0, 3)))
+    W, H = s.getMemorySize(), s.getSpectrumSize()
+    d = jsg.SpectrogramDisplay(s)
+    x = oracle.synth_audio(C, 256 * 1024, seed=seed)
+    img = np.zeros((H, W), np.uint32); full = np.zeros((H, W), np.uint32)
+    lo, hi, at, running = -50.0, 50.0, 0, True
+    cursor_w = 1 + (H < 2048) + 2 * (H < 1024)      # incremental fixed mode draws a wider cursor than a full recolour (:703-720 vs :650-656)
+    for tick in range(25):
+        ev = rng.choice(["tick"] * 6 + ["running", "range", "scheme", "pause"])
+        if ev == "running":
+            running = bool(rng.integers(0, 2))
+            d.setRunning(running)
+        elif ev == "range":
+            lo, hi = float(rng.choice([-90.0, -50.0, -20.0, 10.0])), float(rng.choice([-30.0, 0.0, 50.0]))
+            d.invalidate()
+        elif ev == "scheme":
+            d.setColorSceme(int(rng.integers(0, 7)))
+        elif ev == "pause":
+            s.setPauseMode(bool(rng.integers(0, 2)))
+        for _ in range(int(rng.choice([0, 1, 2, 3, 7, 40]))):
+            if at + n > x.shape[1]:
+                at = 0
+            s.processSynchronBlock(x[:, at:at + n]); at += n
+        nv, pos = d.timerCallback(img, lo, hi)
+        d.invalidate()
+        nv2, pos2 = d.timerCallback(full, lo, hi)
+        assert nv2 == 0 and pos2 == pos, (seed, tick)
+        same = img == full
+        if not running:      # the extra cursor columns pos+1 .. pos+cursor_w-1 are red in the incremental image only
+            for dd in range(1, cursor_w):
+                c = (pos + dd) % W
+                assert (same[:, c] | (img[:, c] == 0xFFFF0000)).all(), (seed, tick, c)
+                same[:, c] = True
+        assert same.all(), (seed, tick, ev, int((~same).sum()))
+    s.close()
+
+
 def test_colormap_non_finite_values_stay_in_range(jsg, oracle, torch_cuda):
     """NaN / +-Inf dB values (the reference's int(NaN) is undefined behaviour) must map to a valid palette entry."""
     torch = torch_cuda
