@@ -913,18 +913,40 @@ static void fill_tables(std::vector<float2>& t, const float* window, double amp)
     }
 }
 
-template <class C, int MIXOP, int OUTK = 0>
-static hipError_t launch_stft_mix(const StftKArgs& ka, dim3 grid, hipStream_t s) {
+// Kernels that need more than 48 KB of dynamic LDS must be told so once per device.  jsg_plan_create does it for every
+// instantiation of the plan's size (so that the first launch may already sit inside a stream capture); the launch path
+// repeats the check for plans that are used on a device other than the one they were created on.
+template <class C, int MIXOP, int OUTK>
+static hipError_t ensure_lds_attr() {
     static std::atomic<bool> attr_done[64];   // set once per device; setting it twice from two threads is harmless
+    if (C::LDS_BYTES <= 48 * 1024) return hipSuccess;
     int dev = 0;
     hipError_t err = hipGetDevice(&dev);
     if (err != hipSuccess) return err;
-    if (C::LDS_BYTES > 48 * 1024 && dev >= 0 && dev < 64 && !attr_done[dev].load(std::memory_order_acquire)) {
+    if (dev >= 0 && dev < 64 && !attr_done[dev].load(std::memory_order_acquire)) {
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_db_kernel<C, MIXOP, OUTK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (err != hipSuccess) return err;
         attr_done[dev].store(true, std::memory_order_release);
     }
+    return hipSuccess;
+}
+
+template <class C>
+static hipError_t ensure_lds_attrs_of_plan() {
+    hipError_t e = ensure_lds_attr<C, 0, 0>();
+    if (e == hipSuccess) e = ensure_lds_attr<C, 1, 0>();
+    if (e == hipSuccess) e = ensure_lds_attr<C, 2, 0>();
+    if (e == hipSuccess) e = ensure_lds_attr<C, 3, 0>();
+    if (e == hipSuccess) e = ensure_lds_attr<C, 0, 1>();
+    if (e == hipSuccess) e = ensure_lds_attr<C, 3, 1>();
+    return e;
+}
+
+template <class C, int MIXOP, int OUTK = 0>
+static hipError_t launch_stft_mix(const StftKArgs& ka, dim3 grid, hipStream_t s) {
+    hipError_t err = ensure_lds_attr<C, MIXOP, OUTK>();
+    if (err != hipSuccess) return err;
     const int flags = (ka.regular ? 1 : 0) | (ka.per_channel ? 2 : 0) | (ka.xcd_remap ? 4 : 0) | (ka.chunked ? 8 : 0);
     hipLaunchKernelGGL((stft_db_kernel<C, MIXOP, OUTK>), grid, dim3(C::WPB * 64), C::LDS_BYTES, s, ka.in, ka.in_pitch, ka.tab, ka.n_frames,
                        ka.first_frame, ka.hop, flags, unsigned(ka.c_begin) | unsigned(ka.c_end) << 16, ka.iters, grid.x, ka.feedblocks, ka);
@@ -1085,7 +1107,15 @@ int jsg_plan_create(jsg_plan** out, int n, const float* window, float power_scal
         (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&stft_db_kernel<Cfg1024, 3>));
         (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&colormap_kernel));
     }
-    hipError_t err = hipMalloc(reinterpret_cast<void**>(&p->d_tab), t.size() * sizeof(float2));
+    hipError_t err = hipSuccess;
+    switch (n) {
+        case 512: err = ensure_lds_attrs_of_plan<Cfg512>(); break;
+        case 1024: err = ensure_lds_attrs_of_plan<Cfg1024>(); break;
+        case 2048: err = ensure_lds_attrs_of_plan<Cfg2048>(); if (err == hipSuccess) err = ensure_lds_attrs_of_plan<Cfg2048B>(); break;
+        case 4096: err = ensure_lds_attrs_of_plan<Cfg4096>(); break;
+        case 8192: err = ensure_lds_attrs_of_plan<Cfg8192>(); break;
+    }
+    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&p->d_tab), t.size() * sizeof(float2));
     if (err == hipSuccess) err = hipMemcpy(p->d_tab, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice);
     if (err != hipSuccess) {
         if (p->d_tab) (void)hipFree(p->d_tab);

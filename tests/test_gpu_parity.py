@@ -515,6 +515,21 @@ def test_launches_are_graph_capturable(jsg, oracle, torch_cuda):
     g.replay(); g.replay()
     torch.cuda.synchronize()
     assert torch.equal(ring_g[:, :513], ring_e[:, :513]) and torch.equal(img_g, img_e)
+    # a plan whose kernels need > 48 KB of dynamic LDS (2048 points, both plans): capture FIRST, run eagerly afterwards --
+    # the LDS attribute is set when the plan is created, not inside the first (captured) launch
+    n2 = 2048
+    plan2 = jsg.Plan(n2, oracle.window(oracle.WIN_HANN, n2))
+    for C in (2, 6):
+        x2 = torch.from_numpy(oracle.synth_audio(C, F * hop + n2, seed=8)).cuda()
+        ring_c = torch.zeros((F, 1056), device="cuda"); ring_x = torch.zeros((F, 1056), device="cuda")
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s2):
+            with torch.cuda.graph(g2, stream=s2):
+                jsg.stft_db(plan2, x2, hop, F, ring_c, mix_mode=jsg.capi.MIX_MIN, stream=s2.cuda_stream)
+        g2.replay()
+        jsg.stft_db(plan2, x2, hop, F, ring_x, mix_mode=jsg.capi.MIX_MIN)
+        torch.cuda.synchronize()
+        assert torch.equal(ring_c, ring_x)
 
 
 @pytest.mark.parametrize("scale", [32768.0, 1e-6])
