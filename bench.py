@@ -11,14 +11,14 @@ result does not depend on how many steps the driver asks for:
 
   c2 (default, BASELINE.json configs[1]): one step = 1024 launches x 4096 frames (mono 48 kHz, 1024-point FFT, hop 512,
       Hann) = 4 194 304 frames.  The launches of a step are independent batches; they are issued by ONE C call
-      (jsg_stft_db_launch_many_threads) round-robin over 8 HIP streams, so the ramp-up and drain of one launch overlap
-      the others.  `value` = frames of all ranks / wall time of the K steps.
+      (jsg_stft_db_launch_many_threads) round-robin over 4 HIP streams, each on its own hardware queue
+      (GPU_MAX_HW_QUEUES=8, set below unless the caller set it), so the ramp-up and drain of one launch overlap the others.  `value` = frames of all ranks / wall time of the K steps.
   c3 (configs[2]): one step = 64 launches x 4096 columns of 8-channel 2048-point frames, 75 % overlap, AbsMean mix,
       issued like c2 over 2 streams.
   c5 (configs[4]): one step = 128 launches x 1875 columns, stereo 96 kHz, 4096-point FFT, 87.5 % overlap, fused
       STFT -> palette index -> ARGB image (jsg_stft_image_launch).  The images of a step are independent; they are
-      replayed from two hipGraphs on two streams (image i on stream i % 2), so the colour kernel of one image runs beside
-      the STFT kernel of the next.
+      replayed from three hipGraphs on three streams (image i on stream i % 3), so the colour kernel of one image runs
+      beside the STFT kernel of the next.
   `--streams 1` times every configuration in order on one stream (that is also what `roofline` reports, see below).
 
 The batches rotate over enough distinct buffers to exceed the 256 MiB Infinity Cache, so every launch streams from
@@ -44,18 +44,24 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues per device (default 4, read when the runtime
+# loads) and torch's own streams take part in that round-robin: with the default, two of the bench's four busy streams can
+# land on ONE hardware queue and serialise (measured: 1.13-1.19e9 frames/s), with eight queues every busy stream has its
+# own (1.32e9).  More than four BUSY queues is what to avoid (5+ streams on 8 queues: 0.5-0.8e9) -- see tools/sweep_overlap.sh.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6300.0  # ... and about 6.3 TB/s achievable (measured streaming copy)
 
 # name -> workload (algorithmic bytes count every input sample once and every output value once)
 CONFIGS = {
-    "c2": dict(n=1024, hop=512, channels=1, frames=4096, fs=48000.0, colour=False, launches_per_step=1024, streams=8,
+    "c2": dict(n=1024, hop=512, channels=1, frames=4096, fs=48000.0, colour=False, launches_per_step=1024, streams=4,
                metric="STFT frames/sec (1024-pt, 50% hop)", unit="frames/s",
                workload="configs[1]: mono 48 kHz, 1024-pt FFT, 512 hop, Hann, 4096 frames/launch, input + dB ring resident in HBM"),
     "c3": dict(n=2048, hop=512, channels=8, frames=4096, fs=48000.0, colour=False, launches_per_step=64, streams=2,
                metric="STFT frames/sec (2048-pt, 75% overlap, 8 channels mixed to one column)", unit="frames/s",
                workload="configs[2]: 8-channel 48 kHz, 2048-pt FFT, 512 hop (75 % overlap), Hann, AbsMean mix, 4096 columns/launch"),
-    "c5": dict(n=4096, hop=512, channels=2, frames=1875, fs=96000.0, colour=True, launches_per_step=128, streams=2,
+    "c5": dict(n=4096, hop=512, channels=2, frames=1875, fs=96000.0, colour=True, launches_per_step=128, streams=3,
                metric="STFT->ARGB columns/sec (4096-pt, 87.5% overlap, stereo 96 kHz)", unit="columns/s",
                workload="configs[4]: stereo 96 kHz, 4096-pt FFT, 512 hop (87.5 % overlap), AbsMean, Jade LUT -50..50 dB -> ARGB image, "
                         "1875 columns (10 s) per launch, fused STFT -> palette index -> ARGB"),
@@ -210,7 +216,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--launches-per-step", type=int, default=0, help="launches in one step (default: the configuration's)")
     ap.add_argument("--nbuf", type=int, default=0, help="distinct batches rotated through (default: enough for > 256 MiB)")
-    ap.add_argument("--streams", type=int, default=0, help="HIP streams of the timed region (default: 8 for c2, 2 for c3 / c5; 1 = in order)")
+    ap.add_argument("--streams", type=int, default=0, help="HIP streams of the timed region (default: 4 for c2, 2 for c3, 3 for c5; 1 = in order)")
     ap.add_argument("--issue-threads", type=int, default=2, help="host threads issuing the launches of a step (c2, streams > 1)")
     ap.add_argument("--blocks-per-cu", type=int, default=1, help="workgroups per CU of each launch when launches overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -498,7 +504,7 @@ def main():
         "config": {"workload": c["workload"],
                    "step": f"{lps} launches x {F} {'columns' if c['colour'] or C > 1 else 'frames'} = {lps * units_per_launch} {c['unit'].split('/')[0]} per step and GPU",
                    "launches_per_step": lps, "frames_per_launch": F * C, "columns_per_launch": F, "channels_per_gpu": C,
-                   "distinct_batches": nbuf, "hip_streams_per_gpu": n_streams,
+                   "distinct_batches": nbuf, "hip_streams_per_gpu": n_streams, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                    "issue": ((("host-issued behind a gate kernel, in order and back to back on one stream (the gate is inside the timed region: this mode is for the tracer)" if args.gate else "host-issued, in order on one stream") if args.no_graph else "hipGraph replay, in order") if n_streams == 1 else (f"{n_streams} hipGraphs per step (independent images, one stream each), replayed together" if c["colour"] else f"one C call per step, {max(1, args.issue_threads)} host thread(s)")),
                    "prewarm_s": round(prewarm_s, 3),
                    "parallelism": f"{world} GPU(s), independent batches, no data-path collective"},
