@@ -80,6 +80,18 @@ __device__ __forceinline__ cf cmul(cf a, cf w) {
     return r;
 }
 
+// (a.x + b.x, a.x - b.x) and (a.y + b.y, a.y - b.y): the real parts, and the imaginary parts, of a + b and a - b side by side
+__device__ __forceinline__ cf addsub_re(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cf addsub_im(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // cos/sin(2*pi*i/32), i = 0..7 (compile-time twiddles of the in-register radix butterflies, first quadrant)
 __device__ constexpr float kCos32[8] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
                                         0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f,
@@ -310,6 +322,15 @@ __device__ __forceinline__ float mix_combine(float acc, float pw) {
     else return pw;                                             // one channel per column: 0 + pw == pw exactly
 }
 
+// the same on a pair (bin k, bin M - k)
+template <int MIXOP>
+__device__ __forceinline__ cf mix_combine2(cf acc, cf pw) {
+    if constexpr (MIXOP == 0) return acc + pw;
+    else if constexpr (MIXOP == 1) return cf{pw.x > acc.x ? pw.x : acc.x, pw.y > acc.y ? pw.y : acc.y};
+    else if constexpr (MIXOP == 2) return cf{pw.x < acc.x ? pw.x : acc.x, pw.y < acc.y ? pw.y : acc.y};
+    else return pw;
+}
+
 #define GETREG_HW_ID ((32 - 1) << 11 | 4)   // s_getreg_b32 hwreg(HW_REG_HW_ID, 0, 32)
 
 // MIXOP: 0 sum over a channel range (AbsMean, Sum), 1 max, 2 min, 3 exactly one channel per column (mono, Left, Right,
@@ -482,13 +503,13 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         e2w[0] = e2r[0] = 0;
     }
 
-    float acc[F][P];
+    cf acc[F][P / 2];   // .x: bin k = ll + L rho of the lower half, .y: its mirror M - k (filled as pairs by the post pass)
     float accNy[F];
     constexpr float init = (MIXOP == 2) ? 1000000.0f : 0.0f;   // reference Spectrogram.cpp:69,78,86
 #pragma unroll
     for (int f = 0; f < F; ++f) {
 #pragma unroll
-        for (int m = 0; m < P; ++m) acc[f][m] = init;
+        for (int m = 0; m < P / 2; ++m) acc[f][m] = cf{init, init};
         accNy[f] = init;
     }
 
@@ -534,7 +555,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
 #pragma unroll
             for (int f = 0; f < F; ++f) {
 #pragma unroll
-                for (int m = 0; m < P; ++m) acc[f][m] += x[f][m].x * x[f][m].y;
+                for (int m = 0; m < P / 2; ++m) acc[f][m] += x[f][m] * x[f][m + P / 2].yx;
                 accNy[f] += x[f][0].x;
             }
         }
@@ -636,8 +657,10 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
             // lower registers rho < P/2: (k, M-k); Z[M-k] is the upper register P-1-rho of lane L-ll (lane 0: its own
             // register P-rho, and Z[M] = Z[0]).  With the window pre-scaled by 1/2 and T = (-i W_N^k) (Z[k] - conj Z[M-k]):
             //     X[k] = S + T,   X[M-k] = conj(S - T),   S = Z[k] + conj Z[M-k]
-            // The self-paired bin M/2 (lane 0, register rho = P/2) is conj Z[M/2].  acc[j] = |X[ll + L j]|^2 (j < P/2),
-            // acc[P/2 + j] = |X[M - ll - L j]|^2, accNy = |X[M/2]|^2.
+            // The self-paired bin M/2 (lane 0, register rho = P/2) is conj Z[M/2].  acc[j] = (|X[ll + L j]|^2,
+            // |X[M - ll - L j]|^2) (j < P/2), accNy = |X[M/2]|^2.  The two powers of a pair are formed side by side: real parts
+            // (S.x + T.x, S.x - T.x) and imaginary parts of X[k] and X[M-k] in one packed add each, then one packed multiply
+            // and one packed fma give both |.|^2, and the mix accumulates the pair with one packed add.
             auto reg_of = [](int rho) { return (rho % U3) * R3 + rho / U3; };
 #pragma unroll
             for (int f = 0; f < F; ++f) {
@@ -662,9 +685,10 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                     const cf z = x[f][reg_of(rho)], p = zq[f][rho];
                     const cf S = add_conj(z, p);
                     const cf T = cmul(sub_conj(z, p), wpost[rho]);
-                    const cf xa = S + T, xb = S - T;
-                    acc[f][rho] = mix_combine<MIXOP>(acc[f][rho], xa.x * xa.x + xa.y * xa.y);
-                    acc[f][P / 2 + rho] = mix_combine<MIXOP>(acc[f][P / 2 + rho], xb.x * xb.x + xb.y * xb.y);
+                    const cf re = addsub_re(S, T), im = addsub_im(S, T);   // (Re X[k], Re X[M-k]), (Im X[k], -Im X[M-k])
+                    cf pw = re * re;
+                    pw = __builtin_elementwise_fma(im, im, pw);
+                    acc[f][rho] = mix_combine2<MIXOP>(acc[f][rho], pw);
                 }
                 {   // bin M/2 (held by the frame's lane 0): the window carries 1/2, so |X|^2 = 4 |Z'|^2.  For single-wave
                     // frames the value is broadcast so that every lane can take part in an unmasked store below.
@@ -697,16 +721,16 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                 } else
                 if (a.exact_div) {   // m_powerfinal[kk] /= m_channels (Spectrogram.cpp:74), IEEE division
 #pragma unroll
-                    for (int m = 0; m < P; ++m) acc[f][m] = acc[f][m] / a.divisor;
+                    for (int m = 0; m < P / 2; ++m) acc[f][m] = cf{acc[f][m].x / a.divisor, acc[f][m].y / a.divisor};
                     accNy[f] = accNy[f] / a.divisor;
                 } else if (a.scale != 1.0f) {   // power-of-two channel count: the same division as an exact scaling
 #pragma unroll
-                    for (int m = 0; m < P; ++m) acc[f][m] *= a.scale;
+                    for (int m = 0; m < P / 2; ++m) acc[f][m] *= a.scale;
                     accNy[f] *= a.scale;
                 }
                 if (!a.linear) {
 #pragma unroll
-                    for (int m = 0; m < P; ++m) acc[f][m] = to_db(acc[f][m]);
+                    for (int m = 0; m < P / 2; ++m) acc[f][m] = cf{to_db(acc[f][m].x), to_db(acc[f][m].y)};
                     accNy[f] = to_db(accNy[f]);
                 }
                 if constexpr (L == 32) {
@@ -717,10 +741,11 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                     // 32 rho + lane of the lower frame over all 64 lanes and register rho + 1 the same bins of the upper
                     // frame -- 256 contiguous bytes per store instruction, as in the 64-lane plans.
 #pragma unroll
-                    for (int m = 0; m < P; m += 2) {
-                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[f][m]), __float_as_uint(acc[f][m + 1]), false, false);
-                        acc[f][m] = __uint_as_float(sw[0]);
-                        acc[f][m + 1] = __uint_as_float(sw[1]);
+                    for (int m = 0; m < P / 2; m += 2) {
+                        const auto lo = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[f][m].x), __float_as_uint(acc[f][m + 1].x), false, false);
+                        const auto hi = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[f][m].y), __float_as_uint(acc[f][m + 1].y), false, false);
+                        acc[f][m] = cf{__uint_as_float(lo[0]), __uint_as_float(hi[0])};
+                        acc[f][m + 1] = cf{__uint_as_float(lo[1]), __uint_as_float(hi[1])};
                     }
                 }
                 // column of the frame whose bins register rho holds after the swap (L == 32), else this lane's own
@@ -737,11 +762,11 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                     for (int rho = 0; rho < P / 2; ++rho) {
                         unsigned char* d = (L == 32 && (rho & 1)) ? icB : icA;
                         const int k = lw + LW * (L == 32 ? rho / 2 : rho);
-                        d[k] = (unsigned char)color_index(acc[f][rho], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
-                        d[M - k] = (unsigned char)color_index(acc[f][P / 2 + rho], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
+                        d[k] = (unsigned char)color_index(acc[f][rho].x, a.vmin, a.vmax, a.top, a.mult, a.n_colors);
+                        d[M - k] = (unsigned char)color_index(acc[f][rho].y, a.vmin, a.vmax, a.top, a.mult, a.n_colors);
                     }
                     if (L <= 64 || ll == 0) ic[M / 2] = (unsigned char)color_index(accNy[f], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
-                } else if (C::ABL == 2 ? (acc[f][0] == 12345.678f) : true) {
+                } else if (C::ABL == 2 ? (acc[f][0].x == 12345.678f) : true) {
                     // non-temporal dword stores, 256 contiguous bytes of the column per instruction (streaming the columns out
                     // instead of leaving them dirty in L2 removed the end-of-kernel write-back)
                     const long long cofs = a.per_channel ? (long long)c0 * a.out_cpitch : 0ll;
@@ -752,13 +777,13 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                     for (int rho = 0; rho < P / 2; ++rho) {
                         float* d = (L == 32 && (rho & 1)) ? dstB : dstA;
                         const int k = lw + LW * (L == 32 ? rho / 2 : rho);
-                        __builtin_nontemporal_store(acc[f][rho], &d[k]);
-                        __builtin_nontemporal_store(acc[f][P / 2 + rho], &d[M - k]);
+                        __builtin_nontemporal_store(acc[f][rho].x, &d[k]);
+                        __builtin_nontemporal_store(acc[f][rho].y, &d[M - k]);
                     }
                     if (L <= 64 || ll == 0) __builtin_nontemporal_store(accNy[f], &dst[M / 2]);   // L <= 64: uniform over the frame's lanes
                 }
 #pragma unroll
-                for (int m = 0; m < P; ++m) acc[f][m] = init;
+                for (int m = 0; m < P / 2; ++m) acc[f][m] = cf{init, init};
                 accNy[f] = init;
             }
         }
