@@ -730,7 +730,11 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                 }
                 if (!a.linear) {
 #pragma unroll
-                    for (int m = 0; m < P / 2; ++m) acc[f][m] = cf{to_db(acc[f][m].x), to_db(acc[f][m].y)};
+                    for (int m = 0; m < P / 2; ++m) {   // to_db() of both values of a pair: packed add and multiply around the two v_log
+                        cf t = acc[f][m] + cf{1e-11f, 1e-11f};
+                        t = cf{__builtin_amdgcn_logf(t.x), __builtin_amdgcn_logf(t.y)};
+                        acc[f][m] = t * cf{3.0102999566398120f, 3.0102999566398120f};
+                    }
                     accNy[f] = to_db(accNy[f]);
                 }
                 if constexpr (L == 32) {
