@@ -102,6 +102,19 @@ __device__ constexpr float kSin32[8] = {0.0f, 0.19509032201612826785f, 0.3826834
                                         0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f,
                                         0.98078528040323044913f};
 
+// cos/sin(2*pi*i/64), i = 0..15: the uniform factors W_64^rho of the factorised post-pass twiddles (Cfg::TWF)
+__device__ constexpr float kCos64[16] = {1.00000000000000000000f, 0.99518472667219692873f, 0.98078528040323043058f, 0.95694033573220882438f, 0.92387953251128673848f, 0.88192126434835504956f, 0.83146961230254523567f, 0.77301045336273699338f, 0.70710678118654757274f, 0.63439328416364548779f, 0.55557023301960228867f, 0.47139673682599780857f, 0.38268343236508983729f, 0.29028467725446233105f, 0.19509032201612833135f, 0.09801714032956077016f};
+__device__ constexpr float kSin64[16] = {0.00000000000000000000f, 0.09801714032956060363f, 0.19509032201612824808f, 0.29028467725446233105f, 0.38268343236508978178f, 0.47139673682599764204f, 0.55557023301960217765f, 0.63439328416364548779f, 0.70710678118654746172f, 0.77301045336273699338f, 0.83146961230254523567f, 0.88192126434835493853f, 0.92387953251128673848f, 0.95694033573220893540f, 0.98078528040323043058f, 0.99518472667219681771f};
+
+// a * w with a wave-uniform w (scalar registers; same arithmetic as cmul)
+__device__ __forceinline__ cf cmul_s(cf a, cf w) {
+    cf r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+        : "=&v"(r) : "v"(a), "s"(w));
+    return r;
+}
+
 // v * exp(-2*pi*i*Q/R) for a first-quadrant exponent (Q < R/4); exponents R/4 <= J < R/2 are this times a pending -i
 template <int Q, int R>
 __device__ __forceinline__ cf mul_w_q1(cf v) {
@@ -186,9 +199,14 @@ __device__ __forceinline__ cf to_cf(const f2u& v) { return cf{v.x, v.y}; }
 // ABL:  development ablations (builds with -DJSG_X_ABL=n): 1 = memory traffic only, 2 = compute only, 3 = in-kernel
 //   stamps, 5 = return at once (launch cost of the kernel's resource footprint).
 template <int N_, int R1_, int R2_, int R3_, int L_, int S1_, int AX_, int AY_, int AZ_, int WPB_, int TLOC_, int WPS_,
-          int FPW_ = 1, int ABL_ = 0>
+          int FPW_ = 1, int ABL_ = 0, int TWF_ = 0>
 struct Cfg {
     static constexpr int ABL = ABL_;
+    // TWF: factorised twiddle tables (for plans whose full lane tables do not fit beside the exchange buffers).  The stage-2
+    // twiddle W_M^(n3 (k1 + R1 k2)) is read as B[n3][k2] = W_(M/R1)^(n3 k2) (one row per n3, shared by the lanes) times the
+    // lane's constant A[v] = W_M^(n3 k1); the post-pass twiddle -i W_N^(ll + L rho) as the lane's constant C = -i W_N^ll times
+    // the wave-uniform W_(N/L)^rho (compile-time constants, N / L = 64).  One more complex multiply per value, 24 KB less LDS.
+    static constexpr bool TWF = TWF_ != 0;
     static constexpr int N = N_, M = N_ / 2, R1 = R1_, R2 = R2_, R3 = R3_, L = L_;
     static constexpr int P = M / L;                  // complex values per lane
     static constexpr int U1 = P / R1, U2 = P / R2, U3 = P / R3;
@@ -212,8 +230,11 @@ struct Cfg {
     // R1 + 2 (16-byte aligned rows whose 16-byte chunks fall into different banks for the n2 groups of a wave).
     static constexpr int TS1 = R1_ + 2;
     static constexpr int tab_idx(int j, int e) { return ((j / 2) * L_ + e) * 2 + j % 2; }
-    static constexpr int TAB_WIN = 0, TAB_TW1 = P * TL, TAB_TW2 = TAB_TW1 + R2_ * TS1, TAB_POST = TAB_TW2 + (TWO_STAGE ? 0 : P * TL);
-    static constexpr int TAB_ELEMS = TAB_POST + (P / 2) * TL;
+    static constexpr int TSB = R2_ + 2;              // TWF: row stride of B (16-byte aligned rows in different banks)
+    static constexpr int TAB_WIN = 0, TAB_TW1 = P * TL, TAB_TW2 = TAB_TW1 + R2_ * TS1;
+    static constexpr int TAB_A = TAB_TW2 + R3_ * TSB;                                   // TWF: [U2][TL] behind B
+    static constexpr int TAB_POST = TWF ? TAB_A + U2 * TL : TAB_TW2 + (TWO_STAGE ? 0 : P * TL);   // TWF: C[TL]
+    static constexpr int TAB_ELEMS = TAB_POST + (TWF ? TL : (P / 2) * TL);
     static constexpr int e1max = (R1 - 1) * S1 + M / R1;
     static constexpr int e2max = TWO_STAGE ? 0 : (R1 - 1) * AX + (R2 - 1) * AY + (R3 - 1) * AZ + 1;
     static constexpr int raw = e1max > e2max ? (e1max > M + 1 ? e1max : M + 1) : (e2max > M + 1 ? e2max : M + 1);
@@ -226,6 +247,7 @@ struct Cfg {
     static_assert(FPW == 1 || L == 64, "interleaved frames: one-wavefront-per-frame plans only");
     static_assert(TLOC == 0 || TLOC == 1, "lane tables in registers: removed (DESIGN.md, tried and measured)");
     static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget of one CU");
+    static_assert(!TWF || (L_ == 64 && N_ / L_ == 64 && L_ % R3_ == 0 && !TWO_STAGE && TLOC_ == 1), "factorised tables: one wavefront per 4096-point frame");
 };
 
 #ifndef JSG_X_ABL
@@ -260,6 +282,7 @@ using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, JSG_X_WPB2048, 1, JSG_X_W
 // The launcher picks by the number of channels mixed into a column (stft_launch_impl).
 using Cfg2048B = Cfg<2048, 32, 32, 1, 32, 34, 0, 0, 0, 8, 1, 1>;
 constexpr int k2048B_min_channels = 3;   // channels mixed into one column from which the two-stage plan is the faster one
+constexpr int k4096B_min_channels = 3;   // ... and the one-wavefront-per-frame 4096-point plan
 #ifndef JSG_X_WPB4096
 #define JSG_X_WPB4096 4
 #endif
@@ -269,7 +292,14 @@ constexpr int k2048B_min_channels = 3;   // channels mixed into one column from 
 #ifndef JSG_X_TLOC4096
 #define JSG_X_TLOC4096 1
 #endif
-using Cfg4096 = Cfg<4096, 16, 8, 16, 128, 144, 1, 272, 17, JSG_X_WPB4096, JSG_X_TLOC4096, JSG_X_WPS4096>;    // two wavefronts per frame, two frames per workgroup
+using Cfg4096 = Cfg<4096, 16, 8, 16, 128, 144, 1, 272, 17, JSG_X_WPB4096, JSG_X_TLOC4096, JSG_X_WPS4096>;
+// 4096 points with ONE wavefront per frame: 8*16*16, 32 complex values per lane, both exchanges wave-private (no workgroup
+// barrier at all), one 8-wave workgroup per CU.  8 x 17.6 KB of exchange leave 22 KB of LDS for tables, so only the window
+// and the stage-1 rows are kept whole and the other two tables are factorised (Cfg::TWF: one more complex multiply per
+// value).  Like Cfg2048B it trades waves per SIMD for independence of the waves: measured (abbench --cfg x4096, 16 384 FFTs,
+// us three-stage two-wave plan -> this one) 8 ch 56.4 -> 48.4, 4 ch 57.2 -> 52.5, 2 ch 59.4 -> 60.6 (61.4 -> 67.4 at 50 %
+// overlap), 1 ch 66.4 -> 79.1: it is the plan of the launches that mix >= 3 channels into a column.
+using Cfg4096B = Cfg<4096, 8, 16, 16, 64, 272, 276, 17, 1, 8, 1, 1, 1, 0, 1>;    // two wavefronts per frame, two frames per workgroup
 using Cfg8192 = Cfg<8192, 16, 16, 16, 256, 272, 1, 272, 17, 4, 0, 1>;   // four wavefronts per frame, one frame per workgroup
 // (frames of more than one wavefront exchange through the workgroup barrier, so every further frame in the workgroup joins
 // five barriers per FFT: 8-wave workgroups were 9-15 % slower, 12-wave ones 30 %)
@@ -469,6 +499,14 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     } else {
         tBase = reinterpret_cast<const cf*>(a.tab);
     }
+    cf twA[C::TWF ? U2 : 1], twC = {0.f, 0.f};           // TWF: this lane's constant factors (see Cfg)
+    int twBrow = 0;
+    if constexpr (C::TWF) {
+#pragma unroll
+        for (int v = 0; v < U2; ++v) twA[v] = tBase[C::TAB_A + v * C::TL + tl];
+        twC = tBase[C::TAB_POST + tl];
+        twBrow = C::TAB_TW2 + (ll % R3) * C::TSB;
+    }
     const cf* const tTw1 = tBase + C::TAB_TW1;       // compact: [n2][TS1], not indexed by lane
     int tw1row[U1];                                   // row of this lane's butterfly u in the stage-1 table
 #pragma unroll
@@ -620,7 +658,11 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
 #pragma unroll
                 for (int k2 = 0; k2 < R2; k2 += 2) {
                     cf w0, w1;
-                    tab2(C::TAB_TW2, v * R2 + k2, w0, w1);
+                    if constexpr (C::TWF) {
+                        const v4f q4 = *reinterpret_cast<const v4f*>(tBase + twBrow + k2);
+                        w0 = cmul(cf{q4.x, q4.y}, twA[v]);
+                        w1 = cmul(cf{q4.z, q4.w}, twA[v]);
+                    } else tab2(C::TAB_TW2, v * R2 + k2, w0, w1);
 #pragma unroll
                     for (int f = 0; f < F; ++f) {
                         lds0[f * C::LDS_ELEMS + e2w[v] + k2 * C::AY] = cmul(t[f][k2], w0);
@@ -679,7 +721,12 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
             frame_sync();   // the next round's exchange stores must stay behind these loads
             cf wpost[P / 2];
 #pragma unroll
-            for (int rho = 0; rho < P / 2; rho += 2) tab2(C::TAB_POST, rho, wpost[rho], wpost[rho + 1]);
+            for (int rho = 0; rho < P / 2; rho += 2) {
+                if constexpr (C::TWF) {
+                    wpost[rho] = cmul_s(twC, cf{kCos64[rho], -kSin64[rho]});
+                    wpost[rho + 1] = cmul_s(twC, cf{kCos64[rho + 1], -kSin64[rho + 1]});
+                } else tab2(C::TAB_POST, rho, wpost[rho], wpost[rho + 1]);
+            }
 #pragma unroll
             for (int f = 0; f < F; ++f) {
 #pragma unroll
@@ -924,12 +971,28 @@ static void fill_tables(std::vector<float2>& t, const float* window, double amp)
             if (k1 == 0) continue;   // the twiddle of k1 = 0 is 1 and never read; k1 sits at column k1 - 1
             t[C::TAB_TW1 + n2 * C::TS1 + k1 - 1] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
         }
+    if constexpr (C::TWF)
+        for (int n3 = 0; n3 < R3; ++n3)
+            for (int k2 = 0; k2 < R2; ++k2) {
+                const double ang = -two_pi * double((long long)n3 * k2 % (M / R1)) / double(M / R1);
+                t[C::TAB_TW2 + n3 * C::TSB + k2] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
+            }
     for (int e = 0; e < TL; ++e) {   // entry e of a table row belongs to lane-in-frame ll (L = 32: both half-waves)
         const int ll = e % L;
         for (int m = 0; m < P; ++m) {   // window pairs: samples 2n, 2n+1 with n = ll + L m
             const int n = ll + L * m;
             const double a2 = 0.5 * amp;   // the paired post pass expects Z/2
             t[C::TAB_WIN + C::tab_idx(m, e)] = make_float2(float(double(window[2 * n]) * a2), float(double(window[2 * n + 1]) * a2));
+        }
+        if constexpr (C::TWF) {   // lane constants A[v] = W_M^(n3 k1), C = -i W_N^ll (the shared B rows are filled above)
+            for (int v = 0; v < C::U2; ++v) {
+                const int t2 = ll + L * v, k1 = t2 / R3, n3 = t2 % R3;
+                const double ang = -two_pi * double((long long)n3 * k1 % M) / double(M);
+                t[C::TAB_A + v * TL + e] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
+            }
+            const double angc = -two_pi * double(ll) / double(N);
+            t[C::TAB_POST + e] = make_float2(float(std::sin(angc)), float(-std::cos(angc)));
+            continue;
         }
         for (int v = 0; v < (C::TWO_STAGE ? 0 : C::U2); ++v)
             for (int k2 = 0; k2 < R2; ++k2) {
@@ -1008,7 +1071,7 @@ struct jsg_plan {
     int device = -1;
     float2* d_tab = nullptr;
     size_t tab_elems = 0;
-    float2* d_tab_b = nullptr;   // 2048 points: lane tables of the two-stage plan (Cfg2048B), behind d_tab in the same allocation
+    float2* d_tab_b = nullptr;   // 2048 / 4096 points: lane tables of the second plan (Cfg2048B / Cfg4096B), behind d_tab in the same allocation
 };
 
 static unsigned long long* g_dev_stamps = nullptr;   // development builds: stamp buffer of the ABL == 3 variants
@@ -1118,7 +1181,15 @@ int jsg_plan_create(jsg_plan** out, int n, const float* window, float power_scal
             t.insert(t.end(), tb.begin(), tb.end());
             break;
         }
-        case 4096: fill_tables<Cfg4096>(t, window, amp); break;
+        case 4096: {   // likewise the two 4096-point plans
+            fill_tables<Cfg4096>(t, window, amp);
+            std::vector<float2> tb;
+            fill_tables<Cfg4096B>(tb, window, amp);
+            t.resize((t.size() + 31) / 32 * 32, make_float2(0.f, 0.f));
+            tab_b_at = t.size();
+            t.insert(t.end(), tb.begin(), tb.end());
+            break;
+        }
         case 8192: fill_tables<Cfg8192>(t, window, amp); break;
         default:
             return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_plan_create: FFT size must be 512, 1024, 2048, 4096 or 8192");
@@ -1143,7 +1214,7 @@ int jsg_plan_create(jsg_plan** out, int n, const float* window, float power_scal
         case 512: err = ensure_lds_attrs_of_plan<Cfg512>(); break;
         case 1024: err = ensure_lds_attrs_of_plan<Cfg1024>(); break;
         case 2048: err = ensure_lds_attrs_of_plan<Cfg2048>(); if (err == hipSuccess) err = ensure_lds_attrs_of_plan<Cfg2048B>(); break;
-        case 4096: err = ensure_lds_attrs_of_plan<Cfg4096>(); break;
+        case 4096: err = ensure_lds_attrs_of_plan<Cfg4096>(); if (err == hipSuccess) err = ensure_lds_attrs_of_plan<Cfg4096B>(); break;
         case 8192: err = ensure_lds_attrs_of_plan<Cfg8192>(); break;
     }
     if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&p->d_tab), t.size() * sizeof(float2));
@@ -1267,13 +1338,15 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     if (mixop == 0 && (ka.per_channel || ka.c_end - ka.c_begin == 1) && ka.scale == 1.0f && !ka.exact_div) mixop = 3;
     if (io && (ka.per_channel || (mixop != 0 && mixop != 3)))
         return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_image_launch: AbsMean / Sum / Left / Right mixes only");
-    // 2048 points: the two-stage plan where several channels are mixed into one column, else the three-stage plan (see
-    // Cfg2048B).  The choice depends on the launch geometry only, so the shards / sub-launches of one stream agree bit for bit.
+    // 2048 / 4096 points: the "B" plan (two-stage / one wavefront per frame) where several channels are mixed into one column,
+    // else the other one (see Cfg2048B, Cfg4096B).  The choice depends on the launch geometry only, so the shards / sub-launches of one stream agree bit for bit.
     bool plan_b = false;
-    if (plan->n == 2048) {
-        static const int forced = [] { const char* e = getenv("JSG_2048_PLAN"); return e ? atoi(e) : 0; }();   // development A/B: 2 | 3
+    if (plan->n == 2048 || plan->n == 4096) {
+        static const int forced2048 = [] { const char* e = getenv("JSG_2048_PLAN"); return e ? atoi(e) : 0; }();   // development A/B: 2 = "B" | 3
+        static const int forced4096 = [] { const char* e = getenv("JSG_4096_PLAN"); return e ? atoi(e) : 0; }();
+        const int forced = plan->n == 2048 ? forced2048 : forced4096;
         const int nc = ka.per_channel ? 1 : ka.c_end - ka.c_begin;
-        plan_b = forced == 2 || (forced != 3 && nc >= k2048B_min_channels);
+        plan_b = forced == 2 || (forced != 3 && nc >= (plan->n == 2048 ? k2048B_min_channels : k4096B_min_channels));
         if (plan_b) ka.tab = plan->d_tab_b;
     }
     int tpb = 0;
@@ -1281,7 +1354,7 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
         case 512: tpb = Cfg512::TPB; break;
         case 1024: tpb = Cfg1024::TPB; break;
         case 2048: tpb = plan_b ? Cfg2048B::TPB : Cfg2048::TPB; break;
-        case 4096: tpb = Cfg4096::TPB; break;
+        case 4096: tpb = plan_b ? Cfg4096B::TPB : Cfg4096::TPB; break;
         case 8192: tpb = Cfg8192::TPB; break;
     }
     const long long want = (g->n_frames + tpb - 1) / tpb;
@@ -1306,7 +1379,7 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
         case 512: err = launch_stft<Cfg512>(ka, mixop, grid, s); break;
         case 1024: err = launch_stft<Cfg1024>(ka, mixop, grid, s); break;
         case 2048: err = plan_b ? launch_stft<Cfg2048B>(ka, mixop, grid, s) : launch_stft<Cfg2048>(ka, mixop, grid, s); break;
-        case 4096: err = launch_stft<Cfg4096>(ka, mixop, grid, s); break;
+        case 4096: err = plan_b ? launch_stft<Cfg4096B>(ka, mixop, grid, s) : launch_stft<Cfg4096>(ka, mixop, grid, s); break;
         case 8192: err = launch_stft<Cfg8192>(ka, mixop, grid, s); break;
     }
     if (err != hipSuccess) return jsg_fail_hip(err, "jsg_stft_db_launch");

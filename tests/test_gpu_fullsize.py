@@ -199,7 +199,7 @@ def test_c5_fused_image_equals_two_kernel_image(jsg, oracle, torch_cuda):
 
 
 @pytest.mark.parametrize("n,channels,mix,lo,hi,scheme", [(1024, 1, 0, -50.0, 50.0, 6), (512, 2, 0, -110.0, 0.0, 4), (2048, 3, 0, 20.0, -80.0, 2),
-                                                          (8192, 2, 3, -50.0, 50.0, 6), (1024, 2, 4, 10.0, 10.0, 1)])
+                                                          (8192, 2, 3, -50.0, 50.0, 6), (1024, 2, 4, 10.0, 10.0, 1), (4096, 4, 0, -60.0, 40.0, 5)])
 def test_fused_image_every_plan(jsg, oracle, torch_cuda, n, channels, mix, lo, hi, scheme):
     torch = torch_cuda
     hop, F = n // 4, 300
@@ -221,7 +221,7 @@ def test_fused_image_every_plan(jsg, oracle, torch_cuda, n, channels, mix, lo, h
         jsg.stft_image(plan, d_in, hop, F, d_lut, lo, hi, fused, scratch, feedblocks=4, mix_mode=1)
 
 
-@pytest.mark.parametrize("n,F,C", [(4096, 9000, 2), (8192, 5000, 2), (2048, 20000, 2), (2048, 40001, 4), (512, 40000, 2), (512, 40001, 1)])
+@pytest.mark.parametrize("n,F,C", [(4096, 9000, 2), (8192, 5000, 2), (2048, 20000, 2), (2048, 40001, 4), (4096, 9001, 3), (512, 40000, 2), (512, 40001, 1)])
 def test_persistent_loop_of_every_plan(jsg, oracle, torch_cuda, n, F, C):
     """Launches large enough that every workgroup loops over several frames (iters > 1), incl. the plans whose frames
     span 2 / 4 wavefronts (workgroup barriers inside the loop): spot checks + batching invariance."""

@@ -130,6 +130,15 @@ static const Config kConfigs[] = {
     {"x2048", 2048, 512, 8, 4096, JSG_MIX_ABSMEAN, false},
     {"x2048", 2048, 256, 8, 4096, JSG_MIX_ABSMEAN, false},
     {"x2048", 2048, 128, 8, 4096, JSG_MIX_ABSMEAN, false},
+    // --cfg x4096: 16384 FFTs of 4096 points (which 4096-point plan)
+    {"x4096", 4096, 2048, 1, 16384, JSG_MIX_ABSMEAN, false},
+    {"x4096", 4096, 512, 1, 16384, JSG_MIX_ABSMEAN, false},
+    {"x4096", 4096, 2048, 2, 8192, JSG_MIX_ABSMEAN, false},
+    {"x4096", 4096, 512, 2, 8192, JSG_MIX_ABSMEAN, false},
+    {"x4096", 4096, 2048, 4, 4096, JSG_MIX_ABSMEAN, false},
+    {"x4096", 4096, 512, 4, 4096, JSG_MIX_ABSMEAN, false},
+    {"x4096", 4096, 2048, 8, 2048, JSG_MIX_ABSMEAN, false},
+    {"x4096", 4096, 512, 8, 2048, JSG_MIX_ABSMEAN, false},
     // --cfg c4sweep: the C4 shard (8 channels per GPU, per-channel columns) at other launch sizes
     {"c4sweep", 1024, 512, 8, 1024, JSG_MIX_PER_CHANNEL, false},
     {"c4sweep", 1024, 512, 8, 16384, JSG_MIX_PER_CHANNEL, false},

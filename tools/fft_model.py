@@ -62,6 +62,13 @@ class Plan:
         k1, n3 = t2 // R3, t2 % R3
         return np.exp(-2j * np.pi * (n3 * (k1 + R1 * k2)) / self.M)
 
+    def tw2_factors(self, v, k2, lane):
+        """Cfg::TWF: the stage-2 twiddle as (shared row B[n3][k2]) x (lane constant A[v]); must equal tw2()."""
+        R1, R2, R3 = self.R
+        t2 = lane + LANES * v
+        k1, n3 = t2 // R3, t2 % R3
+        return np.exp(-2j * np.pi * (n3 * k2) / (self.M // R1)), np.exp(-2j * np.pi * (n3 * k1) / self.M)
+
     def post(self, w, k3, lane):
         R1, R2, R3 = self.R
         k = lane + LANES * w + R1 * R2 * k3
@@ -240,7 +247,9 @@ def search(N, R1, R2, R3, L=64):
 # N: (R1, R2, R3, lanes per frame, S1, AX, AY, AZ) -- the plans compiled into jsg_kernels.hip
 CONFIGS = {512: (8, 8, 4, 32, 36, 4, 33, 1), 1024: (8, 8, 8, 64, 72, 9, 72, 2), 2048: (16, 8, 8, 64, 72, 65, 16, 2),
            "2048B": (32, 32, 1, 32, 34, 0, 0, 0),   # two-stage plan of the launches that mix >= 3 channels per column
-           4096: (16, 8, 16, 128, 144, 1, 272, 17), 8192: (16, 16, 16, 256, 272, 1, 272, 17)}
+           4096: (16, 8, 16, 128, 144, 1, 272, 17),
+           "4096B": (8, 16, 16, 64, 272, 276, 17, 1),   # one wavefront per frame, factorised stage-2 / post tables (Cfg::TWF)
+           8192: (16, 16, 16, 256, 272, 1, 272, 17)}
 
 if __name__ == "__main__":
     rng = np.random.default_rng(0)
@@ -258,5 +267,9 @@ if __name__ == "__main__":
         print(f"N={N} radices={(R1, R2, R3)} L={L} P={p.P} S1={p.S1} AX={p.A} AY={p.B} AZ={p.Z} lds={p.lds_elems * 8} B "
               f"injective={p.check_injective()} max err={err:.2e}")
         p.conflicts(verbose=True)
+        if L == 64 and p.P == 32:   # factorised tables of Cfg4096B: the product of the two factors is the full twiddle
+            worst = max(abs(np.prod(p.tw2_factors(v, k2, lane)) - p.tw2(v, k2, lane))
+                        for v in range(p.U[1]) for k2 in range(R2) for lane in range(L))
+            print(f"   factorised stage-2 twiddles: max |B*A - W| = {worst:.1e}")
         tc, ti = p.table_conflicts()
         print(f"   tables   : {tc:5d} LDS cycles for the 16-byte reads of one table row and one stage-1 row per butterfly (ideal {ti})")
