@@ -247,7 +247,7 @@ struct Cfg {
     static_assert(FPW == 1 || L == 64, "interleaved frames: one-wavefront-per-frame plans only");
     static_assert(TLOC == 0 || TLOC == 1, "lane tables in registers: removed (DESIGN.md, tried and measured)");
     static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget of one CU");
-    static_assert(!TWF || (L_ == 64 && N_ / L_ == 64 && L_ % R3_ == 0 && !TWO_STAGE && TLOC_ == 1), "factorised tables: one wavefront per 4096-point frame");
+    static_assert(!TWF || ((N_ / L_ == 64 || N_ / L_ == 32) && L_ % R3_ == 0 && !TWO_STAGE && TLOC_ == 1), "factorised tables: 4096-point plans");
 };
 
 #ifndef JSG_X_ABL
@@ -292,7 +292,10 @@ constexpr int k4096B_min_channels = 3;   // ... and the one-wavefront-per-frame 
 #ifndef JSG_X_TLOC4096
 #define JSG_X_TLOC4096 1
 #endif
-using Cfg4096 = Cfg<4096, 16, 8, 16, 128, 144, 1, 272, 17, JSG_X_WPB4096, JSG_X_TLOC4096, JSG_X_WPS4096>;
+#ifndef JSG_X_TWF4096
+#define JSG_X_TWF4096 0
+#endif
+using Cfg4096 = Cfg<4096, 16, 8, 16, 128, 144, 1, 272, 17, JSG_X_WPB4096, JSG_X_TLOC4096, JSG_X_WPS4096, 1, 0, JSG_X_TWF4096>;
 // 4096 points with ONE wavefront per frame: 8*16*16, 32 complex values per lane, both exchanges wave-private (no workgroup
 // barrier at all), one 8-wave workgroup per CU.  8 x 17.6 KB of exchange leave 22 KB of LDS for tables, so only the window
 // and the stage-1 rows are kept whole and the other two tables are factorised (Cfg::TWF: one more complex multiply per
@@ -723,8 +726,9 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
 #pragma unroll
             for (int rho = 0; rho < P / 2; rho += 2) {
                 if constexpr (C::TWF) {
-                    wpost[rho] = cmul_s(twC, cf{kCos64[rho], -kSin64[rho]});
-                    wpost[rho + 1] = cmul_s(twC, cf{kCos64[rho + 1], -kSin64[rho + 1]});
+                    constexpr int Q = 64 / (C::N / L);   // W_(N/L)^rho as a multiple of 2 pi / 64
+                    wpost[rho] = cmul_s(twC, cf{kCos64[Q * rho], -kSin64[Q * rho]});
+                    wpost[rho + 1] = cmul_s(twC, cf{kCos64[Q * (rho + 1)], -kSin64[Q * (rho + 1)]});
                 } else tab2(C::TAB_POST, rho, wpost[rho], wpost[rho + 1]);
             }
 #pragma unroll
