@@ -303,7 +303,9 @@ using Cfg4096 = Cfg<4096, 16, 8, 16, 128, 144, 1, 272, 17, JSG_X_WPB4096, JSG_X_
 // us three-stage two-wave plan -> this one) 8 ch 56.4 -> 48.4, 4 ch 57.2 -> 52.5, 2 ch 59.4 -> 60.6 (61.4 -> 67.4 at 50 %
 // overlap), 1 ch 66.4 -> 79.1: it is the plan of the launches that mix >= 3 channels into a column.
 using Cfg4096B = Cfg<4096, 8, 16, 16, 64, 272, 276, 17, 1, 8, 1, 1, 1, 0, 1>;    // two wavefronts per frame, two frames per workgroup
-using Cfg8192 = Cfg<8192, 16, 16, 16, 256, 272, 1, 272, 17, 4, 0, 1>;   // four wavefronts per frame, one frame per workgroup
+// four wavefronts per frame, one frame per workgroup.  Its full lane tables (82 KB) do not fit beside the exchange buffer,
+// and reading them from L2 at every use cost 12 %: the factorised set (Cfg::TWF, 40.7 KB) lives in LDS like everywhere else.
+using Cfg8192 = Cfg<8192, 16, 16, 16, 256, 272, 1, 272, 17, 4, 1, 1, 1, 0, 1>;
 // (frames of more than one wavefront exchange through the workgroup barrier, so every further frame in the workgroup joins
 // five barriers per FFT: 8-wave workgroups were 9-15 % slower, 12-wave ones 30 %)
 
