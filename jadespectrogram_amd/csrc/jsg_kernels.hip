@@ -266,11 +266,14 @@ struct Cfg {
 #define JSG_X_WPB2048 4
 #endif
 #ifndef JSG_X_WPS2048
-#define JSG_X_WPS2048 1
+#define JSG_X_WPS2048 3
 #endif
 using Cfg512 = Cfg<512, 8, 8, 4, 32, 36, 4, 33, 1, 8, 1, 2>;   // (a 80-VGPR budget = 3 workgroups per CU measured no faster)
 using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, JSG_X_WPB1024, 1, 2, JSG_X_FPW1024, JSG_X_ABL>;
-using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, JSG_X_WPB2048, 1, JSG_X_WPS2048, JSG_X_FPW2048>;   // (6-, 8-, 12-wave workgroups: no faster)
+#ifndef JSG_X_TWF2048      // factorised stage-2 / post tables (Cfg::TWF): 11.3 instead of 21.2 KB of tables, so that THREE 4-wave
+#define JSG_X_TWF2048 1    // workgroups fit a CU (12 waves instead of 8): stereo launches -9..-13 %, mono -1..-5 %
+#endif
+using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, JSG_X_WPB2048, 1, JSG_X_WPS2048, JSG_X_FPW2048, 0, JSG_X_TWF2048>;   // (6-, 8-, 12-wave workgroups: no faster)
 // 2048 points as TWO radix-32 stages with ONE exchange: 32 lanes per frame, 32 complex values per lane, two frames side by side
 // in a wavefront.  Against the three-stage plan (16*8*8, 64 lanes): the same butterfly count, but 40 % fewer LDS
 // instructions per frame (one exchange of 16 + 16 instead of two of 32 + 32), which is what capped C3 (VALU and LDS
