@@ -38,7 +38,8 @@ class StftArgs(C.Structure):
                 ("feedblocks", C.c_int32), ("mix_mode", C.c_int32), ("first_frame", C.c_int64),
                 ("n_frames", C.c_int64), ("out_db", C.c_void_p), ("out_pitch", C.c_int64),
                 ("out_channel_pitch", C.c_int64), ("ring_width", C.c_int32), ("ring_pos", C.c_int32),
-                ("linear_out", C.c_int32), ("blocks_per_cu", C.c_int32), ("in_samples", C.c_int64)]
+                ("linear_out", C.c_int32), ("blocks_per_cu", C.c_int32), ("in_samples", C.c_int64),
+                ("plan_select", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ColormapArgs(C.Structure):

@@ -286,6 +286,12 @@ using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, JSG_X_WPB2048, 1, JSG_X_W
 using Cfg2048B = Cfg<2048, 32, 32, 1, 32, 34, 0, 0, 0, 8, 1, 1>;
 constexpr int k2048B_min_channels = 3;   // channels mixed into one column from which the two-stage plan is the faster one
 constexpr int k4096B_min_channels = 3;   // ... and the one-wavefront-per-frame 4096-point plan
+// The "B" plans run ONE 8-wave workgroup per CU (16 / 8 frames at a time): a launch with fewer workgroups than this leaves
+// CUs idle where the small workgroups of the other plan would fill them (1024 stereo 2048-point frames: 7.2 vs 13.0 us), so
+// they are used from this many workgroups on (3/4 of the CUs).  Sub-launches of one stream that fall on different sides of
+// the limit therefore agree within the float32 bound, not bit for bit; sub-launches on the same side, and everything with
+// one or two channels per column, agree bit for bit (the engine's per-block launches are always on the small side).
+constexpr long long kB_min_workgroups = 192;
 #ifndef JSG_X_WPB4096
 #define JSG_X_WPB4096 4
 #endif
@@ -768,7 +774,11 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
 
         // ---- last channel of this column: mix epilogue + dB + ring store ----
         const unsigned it = (nc == 1) ? (unsigned)s : (unsigned)s / (unsigned)nc;
+#ifdef JSG_X_NOEPI   // (timing experiment, wrong results) the epilogue only runs for a value that never occurs
+        if ((ONE || s - (int)it * nc == nc - 1) && acc[0][0].x == 12345.678f) {
+#else
         if (ONE || s - (int)it * nc == nc - 1) {
+#endif
             if constexpr (C::ABL == 3) { if (s == 0) st2 = __builtin_readcyclecounter(); }
 #pragma unroll
             for (int f = 0; f < F; ++f) {
@@ -1353,9 +1363,11 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     if (plan->n == 2048 || plan->n == 4096) {
         static const int forced2048 = [] { const char* e = getenv("JSG_2048_PLAN"); return e ? atoi(e) : 0; }();   // development A/B: 2 = "B" | 3
         static const int forced4096 = [] { const char* e = getenv("JSG_4096_PLAN"); return e ? atoi(e) : 0; }();
-        const int forced = plan->n == 2048 ? forced2048 : forced4096;
+        const int forced = g->plan_select == 1 ? 3 : g->plan_select == 2 ? 2 : (plan->n == 2048 ? forced2048 : forced4096);
         const int nc = ka.per_channel ? 1 : ka.c_end - ka.c_begin;
-        plan_b = forced == 2 || (forced != 3 && nc >= (plan->n == 2048 ? k2048B_min_channels : k4096B_min_channels));
+        const int tpb_b = plan->n == 2048 ? Cfg2048B::TPB : Cfg4096B::TPB;
+        plan_b = forced == 2 || (forced != 3 && nc >= (plan->n == 2048 ? k2048B_min_channels : k4096B_min_channels) &&
+                                 g->n_frames >= kB_min_workgroups * tpb_b);
         if (plan_b) ka.tab = plan->d_tab_b;
     }
     int tpb = 0;
@@ -1369,12 +1381,15 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     const long long want = (g->n_frames + tpb - 1) / tpb;
     const int ny = ka.per_channel ? g->channels : 1;
     if (ny > 65535) return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_db_launch: more than 65535 channels in per-channel mode");
-    static const int blocks_per_cu = [] {   // tuning knob (development): JSG_STFT_BLOCKS_PER_CU
+    static const int blocks_per_cu_env = [] {   // tuning knob (development): JSG_STFT_BLOCKS_PER_CU
         const char* e = getenv("JSG_STFT_BLOCKS_PER_CU");
         const int v = e ? atoi(e) : 0;
-        return v > 0 ? v : 8;
+        return v > 0 ? v : 0;
     }();
-    const int bpc = g->blocks_per_cu > 0 ? g->blocks_per_cu : blocks_per_cu;
+    // workgroups per CU of the grid; the rest of the frames is looped over.  The "B" plans hold one workgroup per CU: a grid of
+    // exactly that many keeps the tables and the prefetch pipeline alive across a workgroup's frames (16 384 mono 4096-point
+    // frames: 65 vs 79 us with a grid of 8 per CU); the other plans do best with more workgroups than are resident.
+    const int bpc = g->blocks_per_cu > 0 ? g->blocks_per_cu : (blocks_per_cu_env > 0 ? blocks_per_cu_env : (plan_b ? 1 : 8));
     long long max_blocks = 256ll * bpc / ny;     // resident workgroups; the rest is looped over
     if (max_blocks < 64) max_blocks = 64;
     static const int max_blocks_env = [] { const char* e = getenv("JSG_STFT_MAX_BLOCKS"); return e ? atoi(e) : 0; }();   // development

@@ -262,19 +262,19 @@ class StftLaunch:
 
 def stft_db(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: int | None = None, mix_mode: int = 0,
             first_frame: int = 0, ring_pos: int = 0, linear_out: bool = False, blocks_per_cu: int = 0,
-            stream: int | None = None):
+            stream: int | None = None, plan_select: int = 0):
     """Enqueue one fused STFT->dB launch.  d_in: torch CUDA float32 [C][samples]; d_out: [W][pitch] (or
     [C][W][pitch] with mix_mode PER_CHANNEL).  Frame j starts at sample (j//feedblocks)*n + (j%feedblocks)*hop."""
     import torch
     a = _stft_args(plan, d_in, hop, n_frames, d_out, feedblocks=feedblocks, mix_mode=mix_mode, first_frame=first_frame,
-                   ring_pos=ring_pos, linear_out=linear_out, blocks_per_cu=blocks_per_cu)
+                   ring_pos=ring_pos, linear_out=linear_out, blocks_per_cu=blocks_per_cu, plan_select=plan_select)
     if stream is None:
         stream = torch.cuda.current_stream(d_in.device).cuda_stream
     check(lib().jsg_stft_db_launch(plan._p, C.byref(a), C.c_void_p(stream)))
 
 
 def _stft_args(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: int | None = None, mix_mode: int = 0,
-               first_frame: int = 0, ring_pos: int = 0, linear_out: bool = False, blocks_per_cu: int = 0):
+               first_frame: int = 0, ring_pos: int = 0, linear_out: bool = False, blocks_per_cu: int = 0, plan_select: int = 0):
     import torch
     assert d_in.is_cuda and d_in.dtype == torch.float32 and d_in.dim() == 2 and d_in.stride(1) == 1
     assert d_out.is_cuda and d_out.dtype == torch.float32 and d_out.stride(-1) == 1
@@ -300,6 +300,7 @@ def _stft_args(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: 
     a.ring_pos = ring_pos
     a.linear_out = int(bool(linear_out))
     a.blocks_per_cu = int(blocks_per_cu)
+    a.plan_select = int(plan_select)       # 0 automatic, 1 small-workgroup kernel, 2 "B" kernel (2048 / 4096 points)
     return a
 
 
@@ -333,7 +334,7 @@ def colormap(d_db, d_lut, lo: float, hi: float, *, d_argb=None, d_index=None, co
 
 def stft_image(plan: Plan, d_in, hop: int, n_frames: int, d_lut, lo: float, hi: float, d_argb, d_index_scratch, *,
                feedblocks: int | None = None, mix_mode: int = 0, first_frame: int = 0, ring_pos: int = 0, ring_width: int | None = None,
-               x_first: int | None = None, stream: int | None = None):
+               x_first: int | None = None, stream: int | None = None, plan_select: int = 0):
     """Fused display path (jsg_stft_image_launch): STFT -> 8-bit palette index columns (d_index_scratch, uint8
     [ring_width][pitch >= n/2+1]) -> ARGB rows of d_argb [n/2+1][Wimg]; no dB column is written.  The image equals
     stft_db() + colormap() bit for bit."""
@@ -356,6 +357,7 @@ def stft_image(plan: Plan, d_in, hop: int, n_frames: int, d_lut, lo: float, hi: 
     st.n_frames = n_frames
     st.ring_width = W
     st.ring_pos = ring_pos
+    st.plan_select = int(plan_select)
     del dummy
     a.stft = st
     c = capi.ColormapArgs()

@@ -209,14 +209,15 @@ def test_fused_image_every_plan(jsg, oracle, torch_cuda, n, channels, mix, lo, h
     pitch = (H + 31) // 32 * 32
     d_db = torch.empty((F, pitch), device="cuda")
     d_lut = torch.from_numpy(jsg.colormap_lut(256, scheme)).cuda()
-    two = torch.zeros((H, F), dtype=torch.int32, device="cuda")
-    jsg.stft_db(plan, d_in, hop, F, d_db, feedblocks=4, mix_mode=mix)
-    jsg.colormap(d_db, d_lut, lo, hi, d_argb=two, height=H)
-    fused = torch.zeros_like(two)
-    scratch = torch.zeros((F, (H + 63) // 64 * 64), dtype=torch.uint8, device="cuda")
-    jsg.stft_image(plan, d_in, hop, F, d_lut, lo, hi, fused, scratch, feedblocks=4, mix_mode=mix)
-    torch.cuda.synchronize()
-    assert torch.equal(fused, two)
+    for sel in ((1, 2) if n in (2048, 4096) else (0,)):     # both kernels of the sizes that have two
+        two = torch.zeros((H, F), dtype=torch.int32, device="cuda")
+        jsg.stft_db(plan, d_in, hop, F, d_db, feedblocks=4, mix_mode=mix, plan_select=sel)
+        jsg.colormap(d_db, d_lut, lo, hi, d_argb=two, height=H)
+        fused = torch.zeros_like(two)
+        scratch = torch.zeros((F, (H + 63) // 64 * 64), dtype=torch.uint8, device="cuda")
+        jsg.stft_image(plan, d_in, hop, F, d_lut, lo, hi, fused, scratch, feedblocks=4, mix_mode=mix, plan_select=sel)
+        torch.cuda.synchronize()
+        assert torch.equal(fused, two)
     with pytest.raises(jsg.JsgError):      # Max / Min mixes and tables of more than 256 colours take the two-kernel path
         jsg.stft_image(plan, d_in, hop, F, d_lut, lo, hi, fused, scratch, feedblocks=4, mix_mode=1)
 
@@ -258,13 +259,14 @@ def _random_images(count, seed):
         frames = int(rng.integers(1, 200))
         lo = float(rng.choice([-110.0, -80.0, -50.0, 0.0, 20.0]))
         hi = float(rng.choice([-60.0, 0.0, 10.0, 50.0, 20.0]))
-        out.append((n, channels, mix, fb, frames, lo, hi, int(rng.integers(0, 7))))
+        sel = int(rng.choice([0, 1, 2])) if n in (2048, 4096) else 0
+        out.append((n, channels, mix, fb, frames, lo, hi, int(rng.integers(0, 7)), sel))
     return out
 
 
-@pytest.mark.parametrize("n,channels,mix,fb,frames,lo,hi,scheme",
+@pytest.mark.parametrize("n,channels,mix,fb,frames,lo,hi,scheme,sel",
                          _random_images(int(os.environ.get("JSG_FUZZ_CASES", "24")), int(os.environ.get("JSG_FUZZ_SEED", "5"))))
-def test_seeded_random_fused_images(jsg, oracle, torch_cuda, n, channels, mix, fb, frames, lo, hi, scheme):
+def test_seeded_random_fused_images(jsg, oracle, torch_cuda, n, channels, mix, fb, frames, lo, hi, scheme, sel):
     """Fused STFT -> index -> ARGB against the two-kernel path, bit for bit, over plans / channel counts / mixes / colour
     ranges (swapped and degenerate ranges included) / ragged image widths."""
     torch = torch_cuda
@@ -275,10 +277,10 @@ def test_seeded_random_fused_images(jsg, oracle, torch_cuda, n, channels, mix, f
     d_db = torch.empty((frames, (H + 31) // 32 * 32), device="cuda")
     d_lut = torch.from_numpy(jsg.colormap_lut(256, scheme)).cuda()
     two = torch.zeros((H, frames), dtype=torch.int32, device="cuda")
-    jsg.stft_db(plan, d_in, hop, frames, d_db, feedblocks=fb, mix_mode=mix)
+    jsg.stft_db(plan, d_in, hop, frames, d_db, feedblocks=fb, mix_mode=mix, plan_select=sel)
     jsg.colormap(d_db, d_lut, lo, hi, d_argb=two, height=H)
     fused = torch.zeros_like(two)
     scratch = torch.zeros((frames, (H + 63) // 64 * 64), dtype=torch.uint8, device="cuda")
-    jsg.stft_image(plan, d_in, hop, frames, d_lut, lo, hi, fused, scratch, feedblocks=fb, mix_mode=mix)
+    jsg.stft_image(plan, d_in, hop, frames, d_lut, lo, hi, fused, scratch, feedblocks=fb, mix_mode=mix, plan_select=sel)
     torch.cuda.synchronize()
     assert torch.equal(fused, two)

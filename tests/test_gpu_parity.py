@@ -317,7 +317,8 @@ def test_ragged_frame_counts_two_frames_per_wavefront(jsg, oracle, torch_cuda, n
     W = frames + 2
     pos = W - 1                                                      # frame 0 -> last column, frame 1 -> column 0
     d_out = torch.full((W, H + 5), 7.0, device="cuda")
-    jsg.stft_db(plan, torch.from_numpy(x).cuda(), hop, frames, d_out, feedblocks=4, ring_pos=pos)
+    # plan_select=2: the "B" kernels of 2048 / 4096 points (automatic selection keeps them for launches that fill the GPU)
+    jsg.stft_db(plan, torch.from_numpy(x).cuda(), hop, frames, d_out, feedblocks=4, ring_pos=pos, plan_select=2)
     torch.cuda.synchronize()
     got = d_out.cpu().numpy()
     cols = (pos + np.arange(frames)) % W
@@ -331,10 +332,10 @@ def test_ragged_frame_counts_two_frames_per_wavefront(jsg, oracle, torch_cuda, n
 
 @pytest.mark.parametrize("n", [2048, 4096])
 def test_2048_and_4096_point_plans_agree(jsg, oracle, torch_cuda, n):
-    """The launcher uses the first 2048- / 4096-point plan for one or two channels per column and the "B" plan (two-stage /
-    one wavefront per frame with factorised tables) from three channels on.  Linear power of both against the float64
-    DFT; and the same stream through both (channels duplicated so that the mixes are equal) stays within the float32 bound
-    of one another."""
+    """2048 and 4096 points have two kernels each: the small-workgroup plan and the "B" plan (two-stage / one wavefront per
+    frame with factorised tables; picked automatically for launches that mix >= 3 channels per column and fill the GPU).
+    Linear power of both, for every channel count, against the float64 DFT; and the same stream through both (channels
+    duplicated so that the mixes are equal) stays within the float32 bound of one another."""
     torch = torch_cuda
     hop, K = 512, 10
     x = oracle.synth_audio(4, K * n, seed=11, kind="mix")
@@ -346,16 +347,18 @@ def test_2048_and_4096_point_plans_agree(jsg, oracle, torch_cuda, n):
     fr = (x[:, idx] * win[None, None, :]).astype(np.float32)
     p64 = oracle.power_spectrum_f64(fr)                              # [C][F][H]
     for C in (1, 2, 3, 4):
-        d_out = torch.empty((F, H), device="cuda")
-        jsg.stft_db(plan, torch.from_numpy(x[:C].copy()).cuda(), hop, F, d_out, mix_mode=jsg.capi.MIX_SUM, linear_out=True)
-        torch.cuda.synchronize()
-        worst = assert_power_close(d_out.cpu().numpy(), p64[:C].sum(axis=0), f"{n} points, {C} channels summed")
-        assert worst < 1e-5, (C, worst)
+        for sel in (1, 2):
+            d_out = torch.empty((F, H), device="cuda")
+            jsg.stft_db(plan, torch.from_numpy(x[:C].copy()).cuda(), hop, F, d_out, mix_mode=jsg.capi.MIX_SUM, linear_out=True,
+                        plan_select=sel)
+            torch.cuda.synchronize()
+            worst = assert_power_close(d_out.cpu().numpy(), p64[:C].sum(axis=0), f"{n} points, {C} channels summed, kernel {sel}")
+            assert worst < 1e-5, (C, sel, worst)
     # one channel four times: the AbsMean of four equal channels is the channel itself up to one rounding of the sum
     one = torch.from_numpy(x[:1].copy()).cuda()
     d1 = torch.empty((F, H), device="cuda"); d4 = torch.empty((F, H), device="cuda")
-    jsg.stft_db(plan, one, hop, F, d1, linear_out=True)
-    jsg.stft_db(plan, one.repeat(4, 1).contiguous(), hop, F, d4, linear_out=True)
+    jsg.stft_db(plan, one, hop, F, d1, linear_out=True, plan_select=1)
+    jsg.stft_db(plan, one.repeat(4, 1).contiguous(), hop, F, d4, linear_out=True, plan_select=2)
     torch.cuda.synchronize()
     a, b = d1.cpu().numpy().astype(np.float64), d4.cpu().numpy().astype(np.float64)
     peak = p64[0].max(axis=-1, keepdims=True)
@@ -375,14 +378,15 @@ def _random_geometries(count, seed):
         hop = n // feedblocks if feedblocks != 10 else [51, 102, 205, 410, 819][[512, 1024, 2048, 4096, 8192].index(n)]
         frames = int(rng.integers(1, 70))
         extra = int(rng.integers(0, 4))
-        out.append((n, channels, mix, feedblocks, hop, frames, extra))
+        sel = int(rng.choice([0, 1, 2])) if n in (2048, 4096) else 0      # which of the two 2048- / 4096-point kernels
+        out.append((n, channels, mix, feedblocks, hop, frames, extra, sel))
     return out
 
 
 # JSG_FUZZ_CASES / JSG_FUZZ_SEED widen the sweep for a one-off campaign (tools/README.md); the suite runs 48 fixed cases
-@pytest.mark.parametrize("n,channels,mix,feedblocks,hop,frames,extra",
+@pytest.mark.parametrize("n,channels,mix,feedblocks,hop,frames,extra,sel",
                          _random_geometries(int(os.environ.get("JSG_FUZZ_CASES", "48")), int(os.environ.get("JSG_FUZZ_SEED", "20260"))))
-def test_seeded_random_geometries(jsg, oracle, torch_cuda, n, channels, mix, feedblocks, hop, frames, extra):
+def test_seeded_random_geometries(jsg, oracle, torch_cuda, n, channels, mix, feedblocks, hop, frames, extra, sel):
     """Seeded sweep over plan x channel count x mix x hop pattern x frame count x ring position (every kernel
     instantiation, both 2048-point plans, the perc10 pattern of Spectrogram.cpp:50-55,216) against the float64 DFT."""
     torch = torch_cuda
@@ -394,7 +398,8 @@ def test_seeded_random_geometries(jsg, oracle, torch_cuda, n, channels, mix, fee
     W = frames + extra
     pos = (W - 1) if extra else 0
     d_out = torch.full((W, H + 2), 7.0, device="cuda")
-    jsg.stft_db(plan, torch.from_numpy(x).cuda(), hop, frames, d_out, feedblocks=feedblocks, mix_mode=mix, ring_pos=pos)
+    jsg.stft_db(plan, torch.from_numpy(x).cuda(), hop, frames, d_out, feedblocks=feedblocks, mix_mode=mix, ring_pos=pos,
+                plan_select=sel)
     torch.cuda.synchronize()
     got = d_out.cpu().numpy()
     cols = (pos + np.arange(frames)) % W

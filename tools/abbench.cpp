@@ -130,6 +130,13 @@ static const Config kConfigs[] = {
     {"x2048", 2048, 512, 8, 4096, JSG_MIX_ABSMEAN, false},
     {"x2048", 2048, 256, 8, 4096, JSG_MIX_ABSMEAN, false},
     {"x2048", 2048, 128, 8, 4096, JSG_MIX_ABSMEAN, false},
+    // --cfg mid: launches that do not fill the GPU with 8- / 16-frame workgroups (which plan for few-second images?)
+    {"mid", 4096, 512, 2, 512, JSG_MIX_ABSMEAN, false},
+    {"mid", 4096, 512, 2, 1024, JSG_MIX_ABSMEAN, false},
+    {"mid", 4096, 512, 1, 1024, JSG_MIX_ABSMEAN, false},
+    {"mid", 2048, 512, 2, 1024, JSG_MIX_ABSMEAN, false},
+    {"mid", 2048, 512, 2, 2048, JSG_MIX_ABSMEAN, false},
+    {"mid", 2048, 512, 1, 2048, JSG_MIX_ABSMEAN, false},
     // --cfg x4096: 16384 FFTs of 4096 points (which 4096-point plan)
     {"x4096", 4096, 2048, 1, 16384, JSG_MIX_ABSMEAN, false},
     {"x4096", 4096, 512, 1, 16384, JSG_MIX_ABSMEAN, false},
