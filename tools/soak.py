@@ -8,7 +8,8 @@ import jadespectrogram_amd as jsg
 from jadespectrogram_amd import capi
 from jadespectrogram_amd.spectrogram import _stft_args
 lib = capi.lib()
-for n, frames, ch in ((512, 3001, 1), (1024, 4096, 1), (1024, 1000, 3), (2048, 2049, 2), (2048, 2049, 5), (4096, 1025, 1), (8192, 513, 2)):
+for n, frames, ch, sel in ((512, 3001, 1, 0), (1024, 4096, 1, 0), (1024, 1000, 3, 0), (2048, 2049, 2, 0), (2048, 2049, 5, 2), (4096, 1025, 1, 0),
+                           (4096, 1025, 3, 2), (8192, 513, 2, 0)):   # sel 2: the "B" kernels of 2048 / 4096 points
     hop = n // 4
     H = n // 2 + 1; pitch = (H + 31) // 32 * 32
     plan = jsg.Plan(n, jsg.window(2, n))
@@ -17,12 +18,12 @@ for n, frames, ch in ((512, 3001, 1), (1024, 4096, 1), (1024, 1000, 3), (2048, 2
     ref = [torch.empty((frames, pitch), device="cuda") for _ in range(B)]
     out = [torch.empty((frames, pitch), device="cuda") for _ in range(B)]
     for b in range(B):
-        jsg.stft_db(plan, xs[b], hop, frames, ref[b], feedblocks=4)
+        jsg.stft_db(plan, xs[b], hop, frames, ref[b], feedblocks=4, plan_select=sel)
     torch.cuda.synchronize()
     reps = 150
     arr = (capi.StftArgs * (B * reps))()
     for i in range(B * reps):
-        a = _stft_args(plan, xs[i % B], hop, frames, out[i % B], feedblocks=4, blocks_per_cu=(i // B) % 3)
+        a = _stft_args(plan, xs[i % B], hop, frames, out[i % B], feedblocks=4, blocks_per_cu=(i // B) % 3, plan_select=sel)
         C.memmove(C.byref(arr, i * C.sizeof(capi.StftArgs)), C.byref(a), C.sizeof(capi.StftArgs))
     streams = [torch.cuda.Stream() for _ in range(S)]
     sarr = (C.c_void_p * S)(*[s.cuda_stream for s in streams])
@@ -35,7 +36,7 @@ for n, frames, ch in ((512, 3001, 1), (1024, 4096, 1), (1024, 1000, 3), (2048, 2
             if not torch.equal(out[b][:, :H], ref[b][:, :H]):
                 bad += 1
             out[b].zero_()
-    print(json.dumps(dict(n=n, frames=frames, channels=ch, launches=6 * B * reps, mismatching_buffers=bad,
+    print(json.dumps(dict(n=n, frames=frames, channels=ch, kernel=sel, launches=6 * B * reps, mismatching_buffers=bad,
                           seconds=round(time.perf_counter() - t0, 2))), flush=True)
     assert bad == 0
 print("soak ok")
