@@ -136,9 +136,9 @@ typedef struct jsg_stft_args {
     int64_t in_samples;      /* floats of every channel row that may be read; the launch is refused (JSG_ERR_INVALID) when
                                 its last frame would read past them.  0: unknown, not checked */
     int32_t plan_select;     /* 2048 / 4096 points have two kernels each.  0: automatic -- the large-workgroup "B" kernel (one 8-wave
-                                workgroup per CU; faster when it can fill the GPU) for launches that mix >= 3 channels per column
-                                AND bring at least 192 of its workgroups (3072 / 1536 columns), the small-workgroup kernel
-                                otherwise.  1: always the small-workgroup kernel, 2: always "B".  The two round differently in
+                                workgroup of 16 / 8 columns per CU; faster when it can fill the GPU) for launches that mix >= 3
+                                channels per column AND fill their rounds of 256 workgroups to at least 87 % (e.g. 3584..4096
+                                columns of 2048 points, or any launch of 7 rounds and more), the small-workgroup kernel otherwise.  1: always the small-workgroup kernel, 2: always "B".  The two round differently in
                                 the last bits (both inside the parity bound): callers that cut one stream into launches of
                                 very different sizes and need bit-identical columns pin one of them.  Other sizes: ignored */
     int32_t reserved;        /* 0 */

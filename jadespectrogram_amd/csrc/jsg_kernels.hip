@@ -286,12 +286,18 @@ using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, JSG_X_WPB2048, 1, JSG_X_W
 using Cfg2048B = Cfg<2048, 32, 32, 1, 32, 34, 0, 0, 0, 8, 1, 1>;
 constexpr int k2048B_min_channels = 3;   // channels mixed into one column from which the two-stage plan is the faster one
 constexpr int k4096B_min_channels = 3;   // ... and the one-wavefront-per-frame 4096-point plan
-// The "B" plans run ONE 8-wave workgroup per CU (16 / 8 frames at a time): a launch with fewer workgroups than this leaves
-// CUs idle where the small workgroups of the other plan would fill them (1024 stereo 2048-point frames: 7.2 vs 13.0 us), so
-// they are used from this many workgroups on (3/4 of the CUs).  Sub-launches of one stream that fall on different sides of
-// the limit therefore agree within the float32 bound, not bit for bit; sub-launches on the same side, and everything with
-// one or two channels per column, agree bit for bit (the engine's per-block launches are always on the small side).
-constexpr long long kB_min_workgroups = 192;
+// The "B" plans run ONE 8-wave workgroup per CU (16 / 8 frames at a time), i.e. a launch proceeds in rounds of 256 workgroups:
+// a launch that fills its last round badly leaves CUs idle where the small workgroups of the other plan would fill them
+// (1024 stereo 2048-point frames: 7.2 vs 13.0 us).  At full rounds "B" is about 13 % faster, so it is used when the rounds of
+// the launch are at least 87 % full (224..256 workgroups, 446..512, ..., everything from 7 rounds on).  Sub-launches of one
+// stream that fall on different sides of that rule therefore agree within the float32 bound, not bit for bit; everything
+// with one or two channels per column, and the engine's per-block launches, always take the small-workgroup plan.
+constexpr double kB_min_round_fill = 0.87;
+static bool b_plan_fills_its_rounds(long long n_frames, int frames_per_workgroup) {
+    const long long want = (n_frames + frames_per_workgroup - 1) / frames_per_workgroup;
+    const long long rounds = (want + 255) / 256;
+    return rounds > 0 && double(want) >= kB_min_round_fill * double(rounds * 256);
+}
 #ifndef JSG_X_WPB4096
 #define JSG_X_WPB4096 4
 #endif
@@ -1367,7 +1373,7 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
         const int nc = ka.per_channel ? 1 : ka.c_end - ka.c_begin;
         const int tpb_b = plan->n == 2048 ? Cfg2048B::TPB : Cfg4096B::TPB;
         plan_b = forced == 2 || (forced != 3 && nc >= (plan->n == 2048 ? k2048B_min_channels : k4096B_min_channels) &&
-                                 g->n_frames >= kB_min_workgroups * tpb_b);
+                                 b_plan_fills_its_rounds(g->n_frames, tpb_b));
         if (plan_b) ka.tab = plan->d_tab_b;
     }
     int tpb = 0;
