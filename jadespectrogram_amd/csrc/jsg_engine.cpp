@@ -305,6 +305,7 @@ int run_blocks(jsg_engine* e, int blocks) {
         a.out_channel_pitch = int64_t(e->W) * e->pitch;
         a.ring_width = e->W;
         a.ring_pos = int((e->mem_counter + skip) % e->W);
+        a.plan_select = 1;   // the ring must not depend on how the host cut the stream into calls: always the same kernel
         const int rc = jsg_stft_db_launch(e->plan, &a, e->stream);
         if (rc != JSG_OK) return e->fail_tls(rc);
         e->mem_counter = int((e->mem_counter + frames) % e->W);

@@ -214,6 +214,28 @@ def test_seeded_random_engine_scenarios(jsg, oracle, seed):
     s.close()
 
 
+@pytest.mark.parametrize("n", [2048, 4096])
+def test_engine_ring_does_not_depend_on_batching_with_many_channels(jsg, oracle, n):
+    """Four channels at 2048 / 4096 points: a stateless launch of this size would switch to the large-workgroup kernel, the
+    engine must not (its ring may not depend on how the host cut the stream into calls): one call with 1024 blocks, calls
+    of 7 blocks and single blocks leave the same bits."""
+    C, blocks = 4, 1024
+    x = oracle.synth_audio(C, blocks * n, seed=3)
+    rings = []
+    for step in (blocks, 7, 1):
+        s = jsg.Spectrogram(C)
+        s.setSamplerate(48000.0); s.setmemoryTime_s(20.0); s.setFFTSize(n); s.setfeed_percent(2)
+        for b in range(0, blocks, step):
+            s.processBlocks(x[:, b * n:min(blocks, b + step) * n])
+        mem = np.zeros((s.getMemorySize(), s.getSpectrumSize()), np.float32)
+        nv, pos = s.getMem(mem)
+        rings.append((nv, pos, mem))
+        s.close()
+    for nv, pos, mem in rings[1:]:
+        assert (nv, pos) == rings[0][:2]
+        assert (mem.view(np.uint32) == rings[0][2].view(np.uint32)).all()
+
+
 def test_silence_and_full_scale(jsg, oracle):
     n = 1024
     s = jsg.Spectrogram(1)
