@@ -278,11 +278,11 @@ using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, JSG_X_WPB2048, 1, JSG_X_W
 // in a wavefront.  Against the three-stage plan (16*8*8, 64 lanes): the same butterfly count, but 40 % fewer LDS
 // instructions per frame (one exchange of 16 + 16 instead of two of 32 + 32), which is what capped C3 (VALU and LDS
 // each about half busy at two waves per SIMD).  One 8-wave workgroup per CU: 16 frames * 8.7 KB of exchange + 21 KB of tables.
-// It needs 210-256 VGPRs (two waves per SIMD, against four of the three-stage plan), so it is the plan of the launches whose
-// time goes into the transform (several channels mixed into one column: the dB epilogue and the column store run once per
-// column, not once per FFT); with one channel per column the epilogue of every round is exposed at two waves per SIMD and
-// the three-stage plan is 13-21 % faster, with two channels they tie (tools/abbench --cfg x2048, table in DESIGN.md).
-// The launcher picks by the number of channels mixed into a column (stft_launch_impl).
+// It needs 210-252 VGPRs (two waves per SIMD) and 156 KB of LDS, so a CU holds exactly one such workgroup, which is launched
+// once per CU and loops over its frames.  For launches that fill the GPU in whole rounds of 256 workgroups it is ahead of the
+// three-stage plan, the more channels are mixed into a column the more (8 ch -10..-13 %, 4 ch -3..-8 %, 1-2 ch level);
+// for anything smaller the 4-frame workgroups of the three-stage plan use more CUs (tools/abbench --cfg x2048 / mid).
+// The launcher picks by channel count and by how well the launch fills its rounds (stft_launch_impl).
 using Cfg2048B = Cfg<2048, 32, 32, 1, 32, 34, 0, 0, 0, 8, 1, 1>;
 constexpr int k2048B_min_channels = 3;   // channels mixed into one column from which the two-stage plan is the faster one
 constexpr int k4096B_min_channels = 3;   // ... and the one-wavefront-per-frame 4096-point plan
