@@ -21,8 +21,8 @@ result does not depend on how many steps the driver asks for:
       beside the STFT kernel of the next.
   `--streams 1` times every configuration in order on one stream (that is also what `roofline` reports, see below).
 
-The batches rotate over enough distinct buffers to exceed the 256 MiB Infinity Cache, so every launch streams from
-and to HBM.  Before the W warm-up steps the same launches run for about 0.3 s so that the clocks have settled.
+The batches rotate over ~1 GB of distinct buffers (about four times the 256 MiB Infinity Cache; `--nbuf` overrides), so every
+launch streams from and to HBM.  Before the W warm-up steps the same launches run for about 0.3 s so that the clocks have settled.
 
 `roofline` is the per-kernel view: the same launches, one at a time in order on ONE stream (a hipGraph replay, timed
 with HIP events on that stream); achieved = algorithmic bytes per launch / average launch duration.  rocprofv3's
@@ -50,6 +50,7 @@ sys.path.insert(0, ROOT)
 # own (1.32e9).  More than four BUSY queues is what to avoid (5+ streams on 8 queues: 0.5-0.8e9) -- see tools/sweep_overlap.sh.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
+ROTATION_BYTES = 1.0e9       # distinct input + output bytes the timed launches rotate over (>> 256 MiB Infinity Cache)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6300.0  # ... and about 6.3 TB/s achievable (measured streaming copy)
 
@@ -158,21 +159,24 @@ def cpu_baseline(c, seconds_budget: float = 10.0):
 
 
 def parity_report(jsg, c, plan, d_in_host, win):
-    """What the tolerances of the parity tests mean on THIS workload (rank 0, N = 1): the share of bins whose relative
-    power error against the float64 DFT exceeds plain 1e-5 and how far below their frame's peak they sit; and the number
-    of colour indices that differ end to end (GPU power -> GPU dB -> GPU index against oracle power -> oracle dB -> oracle
-    index) with the default Jade/256/(-50,50) palette.  Checker code: oracle/ (test infrastructure)."""
+    """What the tolerances of the parity tests mean on THIS workload (rank 0, N = 1), measured on the launch geometry of the timed
+    region -- the same frame count, channel count and automatic kernel selection, so the numbers describe the kernel that is
+    timed (named in "kernel") -- against the float64 DFT on a spread of its columns: the share of bins whose relative power
+    error exceeds plain 1e-5 and how far below their frame's peak they sit; and the number of colour indices that differ end to
+    end (GPU power -> GPU dB -> GPU index against oracle power -> oracle dB -> oracle index) with the default Jade/256/(-50,50)
+    palette.  Checker code: oracle/ (test infrastructure)."""
     import numpy as np
     import torch
     from oracle import jsg_oracle as oracle
     n, hop, C = c["n"], c["hop"], c["channels"]
     H = n // 2 + 1
-    F = min(c["frames"], 512)
+    F = c["frames"]                                   # the timed launch geometry
     x = d_in_host[:, :(F - 1) * hop + n]
     d_x = torch.from_numpy(np.ascontiguousarray(x)).cuda()
     pitch = (H + 31) // 32 * 32
     d_pow = torch.empty((F, pitch), dtype=torch.float32, device="cuda")
     mix = jsg.capi.MIX_ABSMEAN
+    kernel = jsg.stft_kernel_name(plan, d_x, hop, F, d_pow, feedblocks=n // hop, mix_mode=mix)
     jsg.stft_db(plan, d_x, hop, F, d_pow, feedblocks=n // hop, mix_mode=mix, linear_out=True)
     d_db = torch.empty((F, pitch), dtype=torch.float32, device="cuda")
     jsg.stft_db(plan, d_x, hop, F, d_db, feedblocks=n // hop, mix_mode=mix)
@@ -180,11 +184,14 @@ def parity_report(jsg, c, plan, d_in_host, win):
     d_img = torch.zeros((H, F), dtype=torch.int32, device="cuda")
     d_scr = torch.zeros((F, (H + 63) // 64 * 64), dtype=torch.uint8, device="cuda")
     jsg.stft_image(plan, d_x, hop, F, d_lut, -50.0, 50.0, d_img, d_scr, feedblocks=n // hop, mix_mode=mix)
+    d_idx = torch.zeros((H, F), dtype=torch.uint8, device="cuda")      # the image's palette indices (colour loop on the dB ring)
+    jsg.colormap(d_db, d_lut, -50.0, 50.0, d_index=d_idx, n_cols=F, height=H)
     torch.cuda.synchronize()
-    got_p = d_pow[:, :H].cpu().numpy().astype(np.float64)
-    got_idx = d_scr[:, :H].cpu().numpy()
-    idx = (np.arange(F) * hop)[:, None] + np.arange(n)[None, :]
-    frames = (x[:, idx] * win[None, None, :]).astype(np.float32)                       # [C][F][n]
+    cols = np.unique(np.linspace(0, F - 1, min(F, 512)).astype(np.int64))   # the columns the oracle checks
+    got_p = d_pow[:, :H].cpu().numpy()[cols].astype(np.float64)
+    got_idx = d_idx.cpu().numpy()[::-1, :].T[cols]                      # [column][bin] (the image is flipped: y = H-1-bin)
+    idx = (cols * hop)[:, None] + np.arange(n)[None, :]
+    frames = (x[:, idx] * win[None, None, :]).astype(np.float32)                       # [C][F'][n]
     p64 = oracle.power_spectrum_f64(frames)                                            # float64 DFT of the float32 frames
     ref_mixed32 = oracle.mix_channels(p64.astype(np.float32), oracle.MIX_ABSMEAN)      # the reference's float32 channel mix
     ref_p = ref_mixed32.astype(np.float64)
@@ -197,14 +204,21 @@ def parity_report(jsg, c, plan, d_in_host, win):
     pal.set_value_range(-50.0, 50.0)
     ref_idx = pal.index(oracle.to_db(ref_mixed32)).astype(np.uint8)
     flips = int((got_idx != ref_idx).sum())
-    db_err = np.abs(d_db[:, :H].cpu().numpy().astype(np.float64) - oracle.to_db(ref_mixed32).astype(np.float64))
-    return {"frames_checked": int(F), "bins_checked": int(rel.size),
+    # the fused image (jsg_stft_image_launch) must show the same pixels as dB ring + colour loop: compare as ARGB
+    lut = jsg.colormap_lut(256, jsg.capi.CM_JADE).astype(np.uint32) | np.uint32(0xFF000000)
+    img_cols = d_img.cpu().numpy().view(np.uint32)[::-1, :].T[cols]
+    fused_differs = int((img_cols != lut[got_idx]).sum())
+    db_err = np.abs(d_db[:, :H].cpu().numpy()[cols].astype(np.float64) - oracle.to_db(ref_mixed32).astype(np.float64))
+    return {"kernel": kernel, "launch_checked": f"{F} columns x {C} channel(s), automatic kernel selection (the timed geometry)",
+            "columns_checked_against_float64": int(len(cols)), "bins_checked": int(rel.size),
             "frac_bins_rel_power_err_gt_1e-5": float(bad.mean()),
             "those_bins_level_below_frame_peak_db": {"median": float(np.median(level_db[bad])) if bad.any() else None,
                                                      "highest": float(level_db[bad].max()) if bad.any() else None},
             "max_rel_power_err_bins_within_20dB_of_peak": float(rel[strong].max()),
+            "max_err_relative_to_frame_peak": float((np.abs(got_p - ref_p) / peak).max()),
             "max_abs_db_err": float(db_err.max()),
             "colour_index_flips_end_to_end": flips, "pixels_checked": int(got_idx.size),
+            "fused_image_pixels_differing_from_two_kernel_image": fused_differs,
             "note": "float64 DFT of the float32 windowed frames is the yardstick; indices: Jade, 256 colours, -50..50 dB"}
 
 
@@ -292,7 +306,10 @@ def main():
         idx_pitch = (H + 63) // 64 * 64
         img_pitch = (F + 31) // 32 * 32
         per_batch = C * n_samples * 4 + (F * idx_pitch + H * img_pitch * 4 if c["colour"] else F * pitch * 4)
-        nbuf = args.nbuf or max(2, int(300e6 // per_batch) + 1)
+        # Rotation: distinct batches worth ~1 GB, about four times the 256 MiB Infinity Cache.  (Rounds 1-2 rotated over 0.3 GB; the
+        # --nbuf sweep of round 3 -- profiles/r03_c2_nbuf_sweep.json -- showed that a good part of those reads still hit the cache:
+        # C2 1.35e9 frames/s at 0.35 GB, 1.12e9 at 0.7 GB, 1.10e9 at 1.4 GB.)
+        nbuf = args.nbuf or max(2, int(ROTATION_BYTES // per_batch) + 1)
         while n_streams > 1 and nbuf % n_streams:   # a batch must always land on the same stream (its ring is rewritten in order)
             nbuf += 1
         base = synth_audio(C, n_samples + nbuf * 64, fs=c["fs"], seed=1234 + 1000 * rank)   # SURVEY 8d signal
@@ -321,17 +338,21 @@ def main():
             for b in range(min(nbuf, lps)):
                 launch(b, one.cuda_stream)
             torch.cuda.synchronize()
-        if args.no_graph:
-            # Host-issued launches (rocprofv3 does not see kernels inside graph replays).  --gate: BACK TO BACK on the GPU all the
-            # same -- a gate kernel (torch.cuda._sleep: spins for a fixed number of cycles, i.e. it always ends) holds the stream
-            # while the host enqueues the whole group behind it.  Under rocprofv3 the host needs ~11 us per launch; without the
-            # gate every 5 us dispatch of c2 starts on an idle GPU and reads ~1 us longer (6.3 vs 5.7 us).  For the long kernels
-            # of c3 / c5 the tracer's own per-dispatch work shows up instead when they run back to back, so they are traced ungated.
+        gate = {"cycles_per_ms": 0.0, "cycles": 0}
+        if args.gate:
+            # --gate: a gate kernel (torch.cuda._sleep: spins for a fixed number of cycles, i.e. it always ends) holds a stream
+            # while the host enqueues a whole step behind it, so the step's launches run BACK TO BACK on the GPU even when the host
+            # is slow (under rocprofv3 it needs ~11 us per launch).  Calibrated here: spin cycles per millisecond.
             with torch.cuda.stream(one):
                 g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 g0.record(one); torch.cuda._sleep(20_000_000); g1.record(one)
                 torch.cuda.synchronize()
-            gate = {"cycles_per_ms": 20_000_000 / max(g0.elapsed_time(g1), 1e-3), "cycles": 0}
+            gate["cycles_per_ms"] = 20_000_000 / max(g0.elapsed_time(g1), 1e-3)
+        if args.no_graph:
+            # Host-issued launches (rocprofv3 does not see kernels inside graph replays).  With --gate they still run back to
+            # back; without it every 5 us dispatch of c2 starts on an idle GPU and reads ~1 us longer (6.3 vs 5.7 us).  For the
+            # long kernels of c3 / c5 the tracer's own per-dispatch work shows up instead when they run back to back, so they are
+            # traced ungated.
 
             def gated(issue):
                 def run():
@@ -399,7 +420,16 @@ def main():
             sarr = (ctypes.c_void_p * n_streams)(*[st.cuda_stream for st in streams])
 
             def run_step():
+                # --gate (for the tracer, tools/profile_overlap.sh): every stream is held by a bounded spin kernel while the host
+                # enqueues the step, so the launches overlap on the GPU exactly as they do when the host keeps up
+                if args.gate and gate["cycles"]:
+                    for st in streams:
+                        with torch.cuda.stream(st):
+                            torch.cuda._sleep(gate["cycles"])
+                t_i = time.perf_counter()
                 capi.check(lib.jsg_stft_db_launch_many_threads(plan._p, arr, lps, sarr, n_streams, max(1, args.issue_threads)))
+                if args.gate:   # next time the gates outlast the host's issue time by half (bounded: at most 0.5 s)
+                    gate["cycles"] = int(min(500.0, 1.5 * (time.perf_counter() - t_i) * 1e3 + 0.2) * gate["cycles_per_ms"])
         else:
             run_step = replay_inorder
     else:
@@ -505,7 +535,7 @@ def main():
                    "step": f"{lps} launches x {F} {'columns' if c['colour'] or C > 1 else 'frames'} = {lps * units_per_launch} {c['unit'].split('/')[0]} per step and GPU",
                    "launches_per_step": lps, "frames_per_launch": F * C, "columns_per_launch": F, "channels_per_gpu": C,
                    "distinct_batches": nbuf, "hip_streams_per_gpu": n_streams, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
-                   "issue": ((("host-issued behind a gate kernel, in order and back to back on one stream (the gate is inside the timed region: this mode is for the tracer)" if args.gate else "host-issued, in order on one stream") if args.no_graph else "hipGraph replay, in order") if n_streams == 1 else (f"{n_streams} hipGraphs per step (independent images, one stream each), replayed together" if c["colour"] else f"one C call per step, {max(1, args.issue_threads)} host thread(s)")),
+                   "issue": ((("host-issued behind a gate kernel, in order and back to back on one stream (the gate is inside the timed region: this mode is for the tracer)" if args.gate else "host-issued, in order on one stream") if args.no_graph else "hipGraph replay, in order") if n_streams == 1 else (f"{n_streams} hipGraphs per step (independent images, one stream each), replayed together" if c["colour"] else f"one C call per step, {max(1, args.issue_threads)} host thread(s)" + (", every stream held by a gate kernel while the host enqueues the step (the gates are inside the timed region: this mode is for the tracer)" if args.gate else ""))),
                    "prewarm_s": round(prewarm_s, 3),
                    "parallelism": f"{world} GPU(s), independent batches, no data-path collective"},
     }

@@ -144,6 +144,9 @@ typedef struct jsg_stft_args {
     int32_t reserved;        /* 0 */
 } jsg_stft_args;
 int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* args, void* stream);
+/* The kernel configuration jsg_stft_db_launch picks for these arguments on the current device, as text ("Cfg1024", "Cfg2048",
+ * "Cfg2048B", "Cfg4096B", ...; out_len >= 24): lets a benchmark or a test name -- and pin -- the kernel it times or checks. */
+int jsg_stft_kernel_name(const jsg_plan* plan, const jsg_stft_args* args, char* out, int out_len);
 
 /* `count` independent launches issued from one call, launch i on streams[i % n_streams] (hipStream_t handles; NULL or
  * n_streams == 0: the default stream).  For batches that do not depend on each other (distinct input and output
@@ -154,6 +157,20 @@ int jsg_stft_db_launch_many(const jsg_plan* plan, const jsg_stft_args* args, int
  * is kept): for callers whose single issuing thread (~3.5 us per launch) is slower than the GPU. */
 int jsg_stft_db_launch_many_threads(const jsg_plan* plan, const jsg_stft_args* args, int count, void* const* streams,
                                     int n_streams, int n_threads);
+
+/* The overlapped mode as the LIBRARY's default: `count` independent launches (no two of them write the same ring columns),
+ * stream-ordered with respect to `stream` like one launch -- they start after everything that was enqueued on `stream` before
+ * the call, and work enqueued on `stream` after the call sees all their results -- but spread over four streams that the
+ * library owns (created once per device) and issued by two host threads, so that the ramp-up and drain of consecutive
+ * launches overlap (C2: ~3.1 us per 4096-frame launch instead of ~5.1 us in order; bench.py).  The caller neither creates
+ * streams nor knows the good stream count.
+ * Hardware queues: the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues per device (default 4) and
+ * every stream of the process takes part; four BUSY streams that share queues with each other serialise (1.13-1.21e9 instead
+ * of 1.32e9 frames/s at C2).  When the variable is not set, loading libjsg.so sets GPU_MAX_HW_QUEUES=8 for the process (it is
+ * read at the first HIP call, i.e. this works for a host that loads the library before it touches the GPU -- the plugin case;
+ * JSG_KEEP_HW_QUEUES=1 in the environment leaves it alone).  Calls for one device are serialised on the host.  Inside a stream
+ * capture (hipGraph) the launches are issued by the calling thread and become parallel branches of the graph. */
+int jsg_stft_db_launch_batches(const jsg_plan* plan, const jsg_stft_args* args, int count, void* stream);
 
 /* out[i] = 10*log10(power[i]/divisor + 1e-11f), i < count: the tail of the mix (reference Spectrogram.cpp:74,107)
  * for partial sums that were reduced across GPUs (JSG_MIX_SUM).  In place (out == power) is allowed. */

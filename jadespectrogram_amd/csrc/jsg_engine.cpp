@@ -36,6 +36,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -43,6 +44,13 @@
 #include <vector>
 
 #include "jsg_internal.h"
+
+// Hardware queues (jsg.h, jsg_stft_db_launch_batches): the HIP runtime reads GPU_MAX_HW_QUEUES at its first API call.  Unless the
+// user chose a value (or JSG_KEEP_HW_QUEUES is set), give the process eight, so that the engine's two streams, the launch pool's
+// four and the host's own do not end up sharing the default four queues.
+__attribute__((constructor)) static void jsg_default_hw_queues() {
+    if (!getenv("JSG_KEEP_HW_QUEUES")) (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
 
 namespace jsg {
 

@@ -25,6 +25,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -286,17 +287,30 @@ using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, JSG_X_WPB2048, 1, JSG_X_W
 using Cfg2048B = Cfg<2048, 32, 32, 1, 32, 34, 0, 0, 0, 8, 1, 1>;
 constexpr int k2048B_min_channels = 3;   // channels mixed into one column from which the two-stage plan is the faster one
 constexpr int k4096B_min_channels = 3;   // ... and the one-wavefront-per-frame 4096-point plan
-// The "B" plans run ONE 8-wave workgroup per CU (16 / 8 frames at a time), i.e. a launch proceeds in rounds of 256 workgroups:
+// The "B" plans run ONE 8-wave workgroup per CU (16 / 8 frames at a time), i.e. a launch proceeds in rounds of <CU count> workgroups:
 // a launch that fills its last round badly leaves CUs idle where the small workgroups of the other plan would fill them
 // (1024 stereo 2048-point frames: 7.2 vs 13.0 us).  At full rounds "B" is about 13 % faster, so it is used when the rounds of
-// the launch are at least 87 % full (224..256 workgroups, 446..512, ..., everything from 7 rounds on).  Sub-launches of one
+// the launch are at least 87 % full (224..256 workgroups on 256 CUs, 446..512, ..., everything from 7 rounds on).  Sub-launches of one
 // stream that fall on different sides of that rule therefore agree within the float32 bound, not bit for bit; everything
 // with one or two channels per column, and the engine's per-block launches, always take the small-workgroup plan.
 constexpr double kB_min_round_fill = 0.87;
-static bool b_plan_fills_its_rounds(long long n_frames, int frames_per_workgroup) {
+static bool b_plan_fills_its_rounds(long long n_frames, int frames_per_workgroup, int n_cu) {
     const long long want = (n_frames + frames_per_workgroup - 1) / frames_per_workgroup;
-    const long long rounds = (want + 255) / 256;
-    return rounds > 0 && double(want) >= kB_min_round_fill * double(rounds * 256);
+    const long long rounds = (want + n_cu - 1) / n_cu;
+    return rounds > 0 && double(want) >= kB_min_round_fill * double(rounds * n_cu);
+}
+// compute units of the current device (256 on an MI355X in SPX mode, fewer when it is partitioned: CPX / DPX): read once per
+// device from the runtime.  The "one workgroup per CU" grids and the round rule above are sized with it.
+static int cu_count_of_device(int dev) {
+    static std::atomic<int> cached[64];
+    if (dev >= 0 && dev < 64) {
+        const int c = cached[dev].load(std::memory_order_acquire);
+        if (c > 0) return c;
+    }
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    if (dev >= 0 && dev < 64) cached[dev].store(n, std::memory_order_release);
+    return n;
 }
 #ifndef JSG_X_WPB4096
 #define JSG_X_WPB4096 4
@@ -1274,6 +1288,17 @@ struct IndexOut {   // fused display path: where and how the palette indices of 
 };
 }  // namespace
 
+// 2048 / 4096 points: does this launch take the "B" kernel?  (nc: channels combined into one column)
+static bool wants_plan_b(int n, const jsg_stft_args* g, int nc, int n_cu) {
+    if (n != 2048 && n != 4096) return false;
+    static const int forced2048 = [] { const char* e = getenv("JSG_2048_PLAN"); return e ? atoi(e) : 0; }();   // development A/B: 2 = "B" | 3
+    static const int forced4096 = [] { const char* e = getenv("JSG_4096_PLAN"); return e ? atoi(e) : 0; }();
+    const int forced = g->plan_select == 1 ? 3 : g->plan_select == 2 ? 2 : (n == 2048 ? forced2048 : forced4096);
+    const int tpb_b = n == 2048 ? Cfg2048B::TPB : Cfg4096B::TPB;
+    return forced == 2 || (forced != 3 && nc >= (n == 2048 ? k2048B_min_channels : k4096B_min_channels) &&
+                           b_plan_fills_its_rounds(g->n_frames, tpb_b, n_cu));
+}
+
 static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const IndexOut* io, void* stream) {
     if (!plan || !g) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: null argument");
     if (g->n_frames == 0) return JSG_OK;
@@ -1286,11 +1311,10 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch: bad index scratch (needs n_colors <= 256, pitch >= n/2+1, dB mode)");
     if (g->n_frames > g->ring_width)
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: more frames than ring columns in one launch (columns would race)");
-    {
-        int dev = -1;
-        if (hipGetDevice(&dev) != hipSuccess || dev != plan->device)
-            return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: the plan was created on another device");
-    }
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != plan->device)
+        return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: the plan was created on another device");
+    const int n_cu = cu_count_of_device(dev);
     if (g->channels > 65535) return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_db_launch: more than 65535 channels");
     if (g->in_samples != 0) {   // the caller told us how long the channel rows are: refuse to read past them
         const long long j = g->first_frame + g->n_frames - 1;
@@ -1363,19 +1387,12 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     if (mixop == 0 && (ka.per_channel || ka.c_end - ka.c_begin == 1) && ka.scale == 1.0f && !ka.exact_div) mixop = 3;
     if (io && (ka.per_channel || (mixop != 0 && mixop != 3)))
         return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_image_launch: AbsMean / Sum / Left / Right mixes only");
-    // 2048 / 4096 points: the "B" plan (two-stage / one wavefront per frame) where several channels are mixed into one column,
-    // else the other one (see Cfg2048B, Cfg4096B).  The choice depends on the launch geometry only, so the shards / sub-launches of one stream agree bit for bit.
-    bool plan_b = false;
-    if (plan->n == 2048 || plan->n == 4096) {
-        static const int forced2048 = [] { const char* e = getenv("JSG_2048_PLAN"); return e ? atoi(e) : 0; }();   // development A/B: 2 = "B" | 3
-        static const int forced4096 = [] { const char* e = getenv("JSG_4096_PLAN"); return e ? atoi(e) : 0; }();
-        const int forced = g->plan_select == 1 ? 3 : g->plan_select == 2 ? 2 : (plan->n == 2048 ? forced2048 : forced4096);
-        const int nc = ka.per_channel ? 1 : ka.c_end - ka.c_begin;
-        const int tpb_b = plan->n == 2048 ? Cfg2048B::TPB : Cfg4096B::TPB;
-        plan_b = forced == 2 || (forced != 3 && nc >= (plan->n == 2048 ? k2048B_min_channels : k4096B_min_channels) &&
-                                 b_plan_fills_its_rounds(g->n_frames, tpb_b));
-        if (plan_b) ka.tab = plan->d_tab_b;
-    }
+    // 2048 / 4096 points: the "B" plan (two-stage / one wavefront per frame) where several channels are mixed into one column and the
+    // launch fills its rounds, else the other one (see Cfg2048B, Cfg4096B, kB_min_round_fill).  The choice depends on the launch
+    // geometry (channels per column, frames, CU count) only; sub-launches of one stream that fall on different sides of the rule
+    // agree within the float32 bound, not bit for bit (jsg.h: plan_select pins one plan).
+    const bool plan_b = wants_plan_b(plan->n, g, ka.per_channel ? 1 : ka.c_end - ka.c_begin, n_cu);
+    if (plan_b) ka.tab = plan->d_tab_b;
     int tpb = 0;
     switch (plan->n) {
         case 512: tpb = Cfg512::TPB; break;
@@ -1396,7 +1413,7 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     // exactly that many keeps the tables and the prefetch pipeline alive across a workgroup's frames (16 384 mono 4096-point
     // frames: 65 vs 79 us with a grid of 8 per CU); the other plans do best with more workgroups than are resident.
     const int bpc = g->blocks_per_cu > 0 ? g->blocks_per_cu : (blocks_per_cu_env > 0 ? blocks_per_cu_env : (plan_b ? 1 : 8));
-    long long max_blocks = 256ll * bpc / ny;     // resident workgroups; the rest is looped over
+    long long max_blocks = (long long)n_cu * bpc / ny;     // resident workgroups; the rest is looped over
     if (max_blocks < 64) max_blocks = 64;
     static const int max_blocks_env = [] { const char* e = getenv("JSG_STFT_MAX_BLOCKS"); return e ? atoi(e) : 0; }();   // development
     if (max_blocks_env > 0) max_blocks = max_blocks_env;
@@ -1420,6 +1437,19 @@ extern "C" {
 
 int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* g, void* stream) { return stft_launch_impl(plan, g, nullptr, stream); }
 
+// Which kernel configuration jsg_stft_db_launch runs for these arguments on the current device (benchmarks and tests name the
+// kernel they time / check with it; the rule itself: wants_plan_b).
+int jsg_stft_kernel_name(const jsg_plan* plan, const jsg_stft_args* g, char* out, int out_len) {
+    if (!plan || !g || !out || out_len < 24) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_kernel_name: bad argument");
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return jsg_fail(JSG_ERR_NO_DEVICE, "jsg_stft_kernel_name: no device");
+    int nc = g->channels;
+    if (g->mix_mode == JSG_MIX_LEFT || g->mix_mode == JSG_MIX_RIGHT || g->mix_mode == JSG_MIX_PER_CHANNEL) nc = 1;
+    const bool b = wants_plan_b(plan->n, g, nc, cu_count_of_device(dev));
+    std::snprintf(out, size_t(out_len), "Cfg%d%s", plan->n, b ? "B" : "");
+    return JSG_OK;
+}
+
 static int colormap_launch_impl(const jsg_colormap_args* g, const unsigned char* idx_in, long long idx_in_pitch, void* stream);
 
 // Fused display path (reference Spectrogram.cpp:632-648: the colour loop consumes the column it has just been given):
@@ -1431,6 +1461,8 @@ int jsg_stft_image_launch(const jsg_plan* plan, const jsg_stft_image_args* g, vo
     if (!plan || !g) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch: null argument");
     if (g->stft.n_frames == 0) return JSG_OK;
     const jsg_colormap_args& c = g->colour;
+    if (c.ring_width <= 0 || c.col_first < 0)   // (before the modulo below: nothing fatal may cross the C boundary)
+        return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch: bad colour geometry (ring_width <= 0 or col_first < 0)");
     if (c.n_cols != g->stft.n_frames || c.ring_width != g->stft.ring_width || c.height != plan->n / 2 + 1 ||
         (c.col_first % c.ring_width) != g->stft.ring_pos)
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch: the colour loop must cover exactly the columns of the launch");
@@ -1473,11 +1505,71 @@ int jsg_stft_db_launch_many_threads(const jsg_plan* plan, const jsg_stft_args* a
         }
     };
     std::vector<std::thread> th;
-    for (int t = 1; t < n_threads; ++t) th.emplace_back(body, t);
+    int spawn_failed_from = -1;   // std::thread's constructor can throw (std::system_error): nothing may escape the C boundary
+    try {
+        th.reserve(size_t(n_threads));
+        for (int t = 1; t < n_threads; ++t) th.emplace_back(body, t);
+    } catch (...) {
+        spawn_failed_from = int(th.size()) + 1;
+    }
     body(0);
+    if (spawn_failed_from > 0)   // the streams of the threads that could not be started are served by this one
+        for (int t = spawn_failed_from; t < n_threads; ++t) body(t);
     for (auto& x : th) x.join();
     for (int t = 0; t < n_threads; ++t)
         if (rcs[size_t(t)] != JSG_OK) { tls_error() = errs[size_t(t)]; return rcs[size_t(t)]; }
+    return JSG_OK;
+}
+
+// ---- the library's own launch pool: four streams per device, fork / join against the caller's stream ----
+namespace {
+struct LaunchPool {
+    std::mutex mu;                 // one call at a time per device (the fork / join events are reused)
+    bool ready = false;
+    hipStream_t s[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+LaunchPool g_pools[64];
+constexpr int kPoolStreams = 4;    // measured: 3 streams 1.25e9, 4 streams 1.32e9, 5 and more 0.5-0.8e9 frames/s at C2 (tools/sweep_overlap.sh)
+constexpr int kPoolThreads = 2;    // one host thread issues a launch every ~3.5 us, the GPU finishes one every ~3.1 us
+}  // namespace
+
+int jsg_stft_db_launch_batches(const jsg_plan* plan, const jsg_stft_args* args, int count, void* stream) {
+    if (!plan || (!args && count > 0) || count < 0) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch_batches: bad argument");
+    if (count == 0) return JSG_OK;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return jsg_fail(JSG_ERR_NO_DEVICE, "jsg_stft_db_launch_batches: no device");
+    hipStream_t user = reinterpret_cast<hipStream_t>(stream);
+    if (count == 1) return jsg_stft_db_launch(plan, &args[0], stream);
+    LaunchPool& p = g_pools[dev];
+    std::lock_guard<std::mutex> lk(p.mu);
+    hipError_t err = hipSuccess;
+    if (!p.ready) {
+        for (int i = 0; i < kPoolStreams && err == hipSuccess; ++i) {
+            err = hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking);
+            if (err == hipSuccess) err = hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming);
+        }
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&p.fork, hipEventDisableTiming);
+        if (err != hipSuccess) return jsg_fail_hip(err, "jsg_stft_db_launch_batches: creating the launch pool");
+        p.ready = true;
+    }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(user, &cap);
+    const int n_s = count < kPoolStreams ? count : kPoolStreams;
+    // fork: the pool streams start behind everything already enqueued on the caller's stream
+    err = hipEventRecord(p.fork, user);
+    for (int i = 0; i < n_s && err == hipSuccess; ++i) err = hipStreamWaitEvent(p.s[i], p.fork, 0);
+    if (err != hipSuccess) return jsg_fail_hip(err, "jsg_stft_db_launch_batches: fork");
+    void* sv[kPoolStreams];
+    for (int i = 0; i < kPoolStreams; ++i) sv[i] = p.s[i];
+    const int rc = jsg_stft_db_launch_many_threads(plan, args, count, sv, n_s, cap == hipStreamCaptureStatusActive ? 1 : kPoolThreads);
+    // join (also after a failed launch: what was enqueued must still be ordered before the caller's later work)
+    for (int i = 0; i < n_s && err == hipSuccess; ++i) {
+        err = hipEventRecord(p.join[i], p.s[i]);
+        if (err == hipSuccess) err = hipStreamWaitEvent(user, p.join[i], 0);
+    }
+    if (rc != JSG_OK) return rc;
+    if (err != hipSuccess) return jsg_fail_hip(err, "jsg_stft_db_launch_batches: join");
     return JSG_OK;
 }
 

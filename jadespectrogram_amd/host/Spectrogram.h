@@ -85,7 +85,12 @@ public:
 
     // setter
     void setSamplerate(float samplerate) { check(jsg_set_samplerate(m_engine.get(), samplerate)); }
-    void setchannels(size_t newchannels) { check(jsg_set_channels(m_engine.get(), int(newchannels))); }
+    void setchannels(size_t newchannels) {
+        // under the re-blocker's lock, like setFFTSize: processSynchronBlock sizes its pointer table from the engine's channel
+        // count, so the count must not change between that read and jsg_process_block's use of the table
+        std::lock_guard<std::recursive_mutex> lk(syncLock());
+        check(jsg_set_channels(m_engine.get(), int(newchannels)));
+    }
     void setFFTSize(size_t newFFTSize) {
         // engine size and re-blocker size change together under the re-blocker's lock (the reference's m_protect,
         // Spectrogram.cpp:162-167): the audio thread can never hand a block of the old size to the new engine

@@ -14,6 +14,7 @@
 // (a resize wipes the spectrogram's history anyway, reference buildmem, Spectrogram.cpp:213-238).
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cstddef>
 #include <mutex>
 #include <vector>
@@ -34,22 +35,21 @@ public:
     }
     void setDesiredBlockSizeSamples(size_t n) {
         std::lock_guard<std::recursive_mutex> lk(m_syncLock);
-        m_syncBlock = n > 0 ? n : 1;
+        m_syncBlock.store(n > 0 ? n : 1, std::memory_order_release);
         resetFifo();
     }
-    size_t getDesiredBlockSizeSamples() const {
-        std::lock_guard<std::recursive_mutex> lk(m_syncLock);
-        return m_syncBlock;
-    }
+    // lock-free: a getter on the message thread must never make the audio thread's try_lock fail (that would drop a host block)
+    size_t getDesiredBlockSizeSamples() const { return m_syncBlock.load(std::memory_order_acquire); }
 
     void processBlock(juce::AudioBuffer<float>& buffer, juce::MidiBuffer& midi) {
         std::unique_lock<std::recursive_mutex> lk(m_syncLock, std::try_to_lock);
         if (!lk.owns_lock()) return;   // a resize is running on the message thread: skip this host block
         const size_t ch = std::min(m_syncChannels, size_t(buffer.getNumChannels()));
         const size_t n = size_t(buffer.getNumSamples());
+        const size_t block = m_syncBlock.load(std::memory_order_relaxed);   // stable: writers hold m_syncLock
         size_t done = 0;
         while (done < n) {
-            const size_t take = std::min(n - done, m_syncBlock - m_fill);
+            const size_t take = std::min(n - done, block - m_fill);
             for (size_t c = 0; c < m_syncChannels; ++c) {
                 if (c < ch) {
                     const float* src = buffer.getReadPointer(int(c)) + done;
@@ -60,7 +60,7 @@ public:
             }
             m_fill += take;
             done += take;
-            if (m_fill == m_syncBlock) {
+            if (m_fill == block) {
                 processSynchronBlock(m_fifo, midi);
                 m_fill = 0;
             }
@@ -76,12 +76,12 @@ protected:
 
 private:
     void resetFifo() {
-        m_fifo.assign(m_syncChannels, std::vector<float>(m_syncBlock, 0.f));
+        m_fifo.assign(m_syncChannels, std::vector<float>(m_syncBlock.load(std::memory_order_relaxed), 0.f));
         m_fill = 0;
     }
     mutable std::recursive_mutex m_syncLock;
     size_t m_syncChannels = 2;
-    size_t m_syncBlock = 1024;
+    std::atomic<size_t> m_syncBlock{1024};   // written under m_syncLock only; read lock-free by the getter
     size_t m_fill = 0;
     std::vector<std::vector<float>> m_fifo;
 };

@@ -273,6 +273,14 @@ def stft_db(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: int
     check(lib().jsg_stft_db_launch(plan._p, C.byref(a), C.c_void_p(stream)))
 
 
+def stft_kernel_name(plan: Plan, d_in, hop: int, n_frames: int, d_out, **kw) -> str:
+    """The kernel configuration jsg_stft_db_launch picks for this launch ("Cfg1024", "Cfg2048B", ...)."""
+    a = _stft_args(plan, d_in, hop, n_frames, d_out, **kw)
+    buf = C.create_string_buffer(32)
+    check(lib().jsg_stft_kernel_name(plan._p, C.byref(a), buf, 32))
+    return buf.value.decode()
+
+
 def _stft_args(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: int | None = None, mix_mode: int = 0,
                first_frame: int = 0, ring_pos: int = 0, linear_out: bool = False, blocks_per_cu: int = 0, plan_select: int = 0):
     import torch

@@ -287,3 +287,99 @@ def test_seeded_random_fused_images(jsg, oracle, torch_cuda, n, channels, mix, f
     jsg.stft_image(plan, d_in, hop, frames, d_lut, lo, hi, fused, scratch, feedblocks=fb, mix_mode=mix, plan_select=sel)
     torch.cuda.synchronize()
     assert torch.equal(fused, two)
+
+
+def _b_rule(frames, frames_per_workgroup, n_cu, fill=0.87):
+    """The launcher's rule for the "B" kernels (csrc/jsg_kernels.hip: b_plan_fills_its_rounds)."""
+    want = -(-frames // frames_per_workgroup)
+    rounds = -(-want // n_cu)
+    return want >= fill * rounds * n_cu
+
+
+@pytest.mark.parametrize("n,C,F,tpb", [(2048, 8, 4096, 16),      # the C3 bench geometry: 8 ch x 4096 columns
+                                        (4096, 4, 2048, 8)])     # >= 3 ch x >= 1784 columns at 4096 points
+def test_b_kernels_reached_by_automatic_selection(jsg, oracle, torch_cuda, n, C, F, tpb):
+    """The launches the benchmark times (C3) take the "B" kernels through the launcher's own rule, not through plan_select:
+    checked against the float64 DFT, named by jsg_stft_kernel_name, and bit-identical to the pinned "B" kernel.  A wrong
+    table pointer or a wrong fill rule turns this red.  Reference for the mixed column: Spectrogram.cpp:64-108."""
+    torch = torch_cuda
+    hop = 512
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    if not _b_rule(F, tpb, n_cu):
+        pytest.skip(f"{F} columns do not fill the rounds of a {n_cu}-CU device")
+    win = oracle.window(oracle.WIN_HANN, n)
+    plan = jsg.Plan(n, win)
+    fb = n // hop
+    d_in = _stream(torch, C, F * hop + n - hop, seed=21)
+    H, pitch = n // 2 + 1, (n // 2 + 1 + 31) // 32 * 32
+    d_auto = torch.empty((F, pitch), device="cuda")
+    d_b = torch.empty((F, pitch), device="cuda")
+    d_small = torch.empty((F, pitch), device="cuda")
+    assert jsg.stft_kernel_name(plan, d_in, hop, F, d_auto, feedblocks=fb) == f"Cfg{n}B"
+    assert jsg.stft_kernel_name(plan, d_in, hop, F, d_auto, feedblocks=fb, plan_select=1) == f"Cfg{n}"
+    jsg.stft_db(plan, d_in, hop, F, d_auto, feedblocks=fb)
+    jsg.stft_db(plan, d_in, hop, F, d_b, feedblocks=fb, plan_select=2)
+    jsg.stft_db(plan, d_in, hop, F, d_small, feedblocks=fb, plan_select=1)
+    d_pw = torch.empty((F, pitch), device="cuda")
+    jsg.stft_db(plan, d_in, hop, F, d_pw, feedblocks=fb, linear_out=True)
+    torch.cuda.synchronize()
+    assert torch.equal(d_auto[:, :H], d_b[:, :H])
+    assert not torch.equal(d_auto[:, :H], d_small[:, :H])          # the two kernels round differently in the last bits
+    assert (d_auto[:, :H] - d_small[:, :H]).abs().max().item() < 0.05
+    frames = sorted(np.random.default_rng(5).choice(F, 24, replace=False).tolist()) + [0, F - 1]
+    _parseval_check(torch, d_in, d_pw, n, hop, win, frames)
+    _spot_check(oracle, d_in, d_auto[frames][:, :H].cpu().numpy(), n, hop, win, frames)
+
+
+@pytest.mark.parametrize("n,C,tpb", [(2048, 8, 16), (4096, 4, 8)])
+def test_just_below_the_fill_rule_takes_the_small_kernel(jsg, oracle, torch_cuda, n, C, tpb):
+    """One workgroup short of 87 % of a round: automatic selection must equal plan_select=1 bit for bit."""
+    torch = torch_cuda
+    hop = 512
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    F = (int(0.87 * n_cu) - 1) * tpb          # < 87 % of one round of n_cu workgroups
+    assert not _b_rule(F, tpb, n_cu)
+    win = oracle.window(oracle.WIN_HANN, n)
+    plan = jsg.Plan(n, win)
+    fb = n // hop
+    d_in = _stream(torch, C, F * hop + n - hop, seed=22)
+    H, pitch = n // 2 + 1, (n // 2 + 1 + 31) // 32 * 32
+    d_auto = torch.empty((F, pitch), device="cuda")
+    d_small = torch.empty((F, pitch), device="cuda")
+    assert jsg.stft_kernel_name(plan, d_in, hop, F, d_auto, feedblocks=fb) == f"Cfg{n}"
+    jsg.stft_db(plan, d_in, hop, F, d_auto, feedblocks=fb)
+    jsg.stft_db(plan, d_in, hop, F, d_small, feedblocks=fb, plan_select=1)
+    torch.cuda.synchronize()
+    assert torch.equal(d_auto[:, :H], d_small[:, :H])
+    frames = sorted(np.random.default_rng(6).choice(F, 16, replace=False).tolist())
+    _spot_check(oracle, d_in, d_auto[frames][:, :H].cpu().numpy(), n, hop, win, frames)
+
+
+def test_grid_shape_ring_position_and_ring_alignment_do_not_change_the_bits(jsg, oracle, torch_cuda):
+    """Mono launches: one frame per wavefront (many workgroups) against several frames per wavefront (blocks_per_cu = 1, 2),
+    ring wrap, a ring whose columns are only 4-byte aligned, ragged frame counts, 50 % and 75 % overlap: the same bits, and
+    the padding behind a column is never written."""
+    torch = torch_cuda
+    for n, hop in ((1024, 512), (1024, 256), (2048, 1024), (2048, 512)):
+        win = oracle.window(oracle.WIN_HANN, n)
+        plan = jsg.Plan(n, win)
+        H, pitch = n // 2 + 1, (n // 2 + 1 + 31) // 32 * 32
+        for F in (4096, 4099, 777, 8192 + 5):
+            d_in = _stream(torch, 1, F * hop + n - hop, seed=F)
+            ref = torch.empty((F, pitch), device="cuda")
+            jsg.stft_db(plan, d_in, hop, F, ref, feedblocks=n // hop, blocks_per_cu=64)     # enough workgroups for one frame per wave
+            for bpc in (1, 2):
+                got = torch.full((F, pitch), 7.0, device="cuda")
+                pos = F // 3
+                jsg.stft_db(plan, d_in, hop, F, got, feedblocks=n // hop, blocks_per_cu=bpc, ring_pos=pos)
+                torch.cuda.synchronize()
+                assert torch.equal(torch.roll(got, -pos, 0)[:, :H], ref[:, :H]), (n, hop, F, bpc)
+                assert bool((got[:, H:] == 7.0).all())                                  # the padding behind a column is untouched
+            # a ring whose columns are only 4-byte aligned: dword stores, same bits
+            buf = torch.empty(F * (pitch + 1) + 1, device="cuda")
+            odd = buf[1:].as_strided((F, pitch + 1), (pitch + 1, 1))
+            jsg.stft_db(plan, d_in, hop, F, odd, feedblocks=n // hop, blocks_per_cu=1)
+            torch.cuda.synchronize()
+            assert torch.equal(odd[:, :H], ref[:, :H]), (n, hop, F, "odd")
+    frames = sorted(np.random.default_rng(7).choice(F, 16, replace=False).tolist())
+    _spot_check(oracle, d_in, ref[frames][:, :H].cpu().numpy(), n, hop, win, frames)

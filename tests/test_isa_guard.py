@@ -1,0 +1,79 @@
+"""Build-time guard for the counted wait in stft_db_kernel (csrc/jsg_kernels.hip, "lane tables first").
+
+The kernel issues its lane tables as LDS-DMA pieces (global_load_lds_dwordx4), then the F*P loads of its first frame, and
+retires the tables with `s_waitcnt vmcnt(F*P)` + `s_barrier` while the frame is still in flight.  vmcnt counts
+instructions in issue order, so the wait is right only if the compiler emits EXACTLY F*P vector-memory instructions
+between the last table piece and the wait: were a frame load split in two, the barrier would release waves whose tables
+have not landed (silently wrong twiddles); were two merged, the wait would also drain a frame load (slower, still right).
+This test disassembles the device code object and checks the count for every instantiation.  CPU only."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+OBJ = os.path.join(ROOT, "jadespectrogram_amd", "build", "jsg_kernels.o")
+
+VMEM = re.compile(r"^\s*(global_load|global_store|global_atomic|buffer_load|buffer_store|buffer_atomic|flat_load|flat_store|flat_atomic|scratch_load|scratch_store)")
+
+
+def _disassemble(tmp_path):
+    for tool in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump"):
+        if not os.path.exists(os.path.join(LLVM, tool)):
+            pytest.skip(f"{tool} not found under {LLVM}")
+    if not os.path.exists(OBJ):
+        from jadespectrogram_amd import _build
+        _build.build_lib()
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", OBJ, str(tmp_path / "scratch.o")])
+    subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o",
+                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"])
+    return subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co]).decode()
+
+
+def _functions(text):
+    cur, body = None, []
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            if cur:
+                yield cur, body
+            cur, body = m.group(1), []
+        elif cur and line.strip() and not line.startswith("Disassembly"):
+            body.append(line.split("//")[0].strip())
+    if cur:
+        yield cur, body
+
+
+def test_counted_wait_matches_the_emitted_frame_loads(tmp_path):
+    text = _disassemble(tmp_path)
+    checked = 0
+    for name, body in _functions(text):
+        if "stft_db_kernel" not in name and "stft_image_kernel" not in name:
+            continue
+        # Cfg<N, R1, R2, R3, L, S1, AX, AY, AZ, WPB, TLOC, WPS, FPW, ABL, TWF>
+        m = re.search(r"3CfgI(.*?)EE", name)
+        vals = [int(v) for v in re.findall(r"Li(\d+)E", m.group(1))]
+        n, lanes, tloc, fpw = vals[0], vals[4], vals[10], vals[12]
+        if tloc != 1:
+            continue
+        expect = (n // 2 // lanes) * fpw
+        dma = [i for i, ins in enumerate(body) if ins.startswith("global_load_lds_dwordx4") or (ins.startswith("buffer_load_dwordx4") and " lds" in ins)]
+        assert dma, f"{name}: no LDS-DMA table pieces found"
+        bar = next(i for i, ins in enumerate(body) if ins.startswith("s_barrier"))
+        assert dma[-1] < bar or all(d < bar for d in dma), f"{name}: table pieces after the barrier"
+        last_dma = max(d for d in dma if d < bar)
+        # the wait is the instruction in front of the barrier (one asm statement: nothing can be scheduled between them)
+        w = body[bar - 1]
+        mm = re.match(r"s_waitcnt vmcnt\((\d+)\)", w)
+        assert mm, f"{name}: expected the counted wait in front of the first s_barrier, found '{w}'"
+        assert int(mm.group(1)) == expect, f"{name}: waits for vmcnt({mm.group(1)}), the plan has {expect} frame loads"
+        between = [ins for ins in body[last_dma + 1:bar - 1] if VMEM.match(ins)]
+        assert len(between) == expect, (f"{name}: {len(between)} vector-memory instructions between the last table piece and "
+                                        f"s_waitcnt vmcnt({expect}): {between}")
+        assert all(ins.startswith("global_load_dwordx2") for ins in between), f"{name}: unexpected frame-load form {sorted(set(between))[:3]}"
+        checked += 1
+    assert checked >= 40, f"only {checked} instantiations checked"

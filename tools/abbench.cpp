@@ -245,8 +245,12 @@ int main(int argc, char** argv) {
         const size_t in_bytes = size_t(in_pitch) * c.channels * 4, out_bytes = size_t(c.frames) * pitch * planes * 4;
         const int64_t img_pitch = (c.frames + 31) / 32 * 32;
         const size_t img_bytes = c.colour ? size_t(img_pitch) * H * 4 : 0;
-        int nbuf = int(300e6 / double(in_bytes + out_bytes + img_bytes)) + 1;
-        nbuf = std::max(2, std::min(nbuf, 64));
+        // rotation: distinct batches worth AB_ROT_MB (default 1000 MB, about 4x the 256 MiB Infinity Cache -- with the 300 MB of
+        // round 2 a good part of the reads still hit it: bench.py --nbuf sweep, 0.69 -> 0.57 of 8 TB/s at C2)
+        const double rot_bytes = (std::getenv("AB_ROT_MB") ? std::atof(std::getenv("AB_ROT_MB")) : 1000.0) * 1e6;
+        int nbuf = int(rot_bytes / double(in_bytes + out_bytes + img_bytes)) + 1;
+        nbuf = std::max(2, std::min(nbuf, 256));
+        while (nstreams > 1 && nbuf % nstreams) ++nbuf;   // a batch always lands on the same stream
         // seeded input: sine + noise per channel (the shape of SURVEY 8d's signal; exact values do not matter here)
         std::vector<float> hx(size_t(in_pitch) * c.channels);
         uint32_t s = 12345u;
@@ -276,7 +280,7 @@ int main(int argc, char** argv) {
 
         if (std::getenv("AB_FLOOR")) {   // what this launch size costs with no work / as a plain copy (same buffers, same rotation)
             const long long n4 = (long long)(std::min(in_bytes, out_bytes) / 16);
-            const int nwg = (c.frames + 7) / 8;
+            const int nwg = std::getenv("AB_FLOOR_WG") ? std::atoi(std::getenv("AB_FLOOR_WG")) : (c.frames + 7) / 8;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ab_null_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 37 * 1024);
             for (int mode = 0; mode < 2; ++mode) {
                 std::vector<double> t;
@@ -293,6 +297,35 @@ int main(int argc, char** argv) {
                 CK(hipGraphExecDestroy(ge));
                 std::printf("   floor: %-32s graph %7.2f us/launch (min %7.2f)\n", mode == 0 ? "empty kernel, same geometry" : "streaming copy, same bytes",
                             median(t), *std::min_element(t.begin(), t.end()));
+                if (nstreams > 1) {   // the same, host-issued round-robin over the streams (what overlapped launches can reach)
+                    std::vector<double> tm;
+                    for (int r = 0; r < rounds; ++r) {
+                        auto issue_ms = [&](int count) {
+                            auto body = [&](int t) {
+                                (void)hipSetDevice(0);
+                                for (int i = t; i < count; i += nthreads) {
+                                    const int b = i % nbuf;
+                                    hipStream_t st = streams[size_t(b) % streams.size()];
+                                    if (mode == 0) hipLaunchKernelGGL(ab_null_kernel, dim3(nwg), dim3(512), 37 * 1024, st, d_out[b], 0);
+                                    else hipLaunchKernelGGL(ab_copy_kernel, dim3(2048), dim3(256), 0, st, reinterpret_cast<const ab_v4f*>(d_in[b]),
+                                                            reinterpret_cast<ab_v4f*>(d_out[b]), n4);
+                                }
+                            };
+                            if (nthreads <= 1) { body(0); return; }
+                            std::vector<std::thread> th;
+                            for (int t = 0; t < nthreads; ++t) th.emplace_back(body, t);
+                            for (auto& x : th) x.join();
+                        };
+                        issue_ms(std::min(reps, 200));
+                        CK(hipDeviceSynchronize());
+                        const auto t0 = std::chrono::steady_clock::now();
+                        issue_ms(reps);
+                        CK(hipDeviceSynchronize());
+                        tm.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps);
+                    }
+                    std::printf("   floor: %-32s %d streams %7.2f us/launch (min %7.2f)\n", mode == 0 ? "empty kernel, same geometry" : "streaming copy, same bytes",
+                                nstreams, median(tm), *std::min_element(tm.begin(), tm.end()));
+                }
             }
         }
         if (std::getenv("AB_GEO")) {   // empty kernels: what do workgroup size, workgroup count and LDS allocation cost?
