@@ -158,6 +158,58 @@ def cpu_baseline(c, seconds_budget: float = 10.0):
     return res
 
 
+def boundary_latency_subprocess():
+    """What the drop-in sees, part 1 (rank 0, N = 1; started BEFORE this process touches the GPU): the audio-thread call
+    jsg_process_block -- reference call path PluginProcessor.cpp:145-150 -> Spectrogram::processSynchronBlock -- timed in its own
+    small C++ process (tests/cpp/producer_latency_test.cpp, C-ABI only) on the C5 geometry (stereo 96 kHz, 4096 points, ring
+    1875 x 2049) while a consumer thread reads the ring and recolours the 15 MB image without pause (Spectrogram.cpp:590-608)."""
+    import tempfile
+    try:
+        libdir = os.path.join(ROOT, "jadespectrogram_amd")
+        exe = os.path.join(tempfile.gettempdir(), "jsg_bench_producer_latency")
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tests", "cpp", "producer_latency_test.cpp"), "-o", exe, "-L", libdir, "-ljsg",
+                               f"-Wl,-rpath,{libdir}", "-lpthread"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        r = subprocess.run([exe, "400", "300"], capture_output=True, text=True, timeout=120)
+        info = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"call": "jsg_process_block (host planar pointers in, enqueue only), one 4096-sample stereo block per call, 400 calls, 300 us apart",
+                "under": f"a consumer thread alternating jsg_get_mem and jsg_display_update on the 1875 x 2049 ring without pause ({info['reads']} reads meanwhile)",
+                "p50_us": info["p50_us"], "p99_us": info["p99_us"], "max_us_after_first_call": info["max_after_first_us"],
+                "first_call_us": info["first_call_us"],
+                "ring_bit_identical_to_undisturbed_batch_run": info["differing_floats"] == 0 and info["differing_pixels"] == 0}
+    except Exception as e:   # a reported figure, never a reason to lose the bench line
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
+
+
+def boundary_pcie_rate(jsg, c):
+    """What the drop-in sees, part 2: frames/s through the engine fed from HOST memory (jsg_process_blocks: pinned-staging-free
+    H2D copy of a whole batch + one launch), 4096-frame batches of the configuration -- PCIe-inclusive, never the `value`."""
+    import numpy as np
+    import torch
+    n, hop, C = c["n"], c["hop"], c["channels"]
+    blocks = c["frames"] * hop // n                       # fft-size blocks that make c["frames"] columns
+    s = jsg.Spectrogram(C)
+    s.setSamplerate(c["fs"]); s.setmemoryTime_s(60.0); s.setFFTSize(n)
+    s._c(jsg.capi.lib().jsg_set_feed_percent_ext(s._h, 100.0 * hop / n))
+    x = synth_audio(C, blocks * n, fs=c["fs"], seed=99)
+    xp = torch.from_numpy(x).pin_memory().numpy()
+    out = {}
+    for name, buf in (("pageable", x), ("pinned", xp)):
+        for _ in range(3):
+            s.processBlocks(buf)
+        s.sync()
+        K = 40
+        t0 = time.perf_counter()
+        for _ in range(K):
+            s.processBlocks(buf)
+        s.sync()
+        dt = time.perf_counter() - t0
+        out[name] = {"frames_per_s": K * blocks * (n // hop) * C / dt, "us_per_batch": dt / K * 1e6, "h2d_GBps": K * x.nbytes / dt / 1e9}
+    s.close()
+    return {"call": f"jsg_process_blocks, host buffers in, batches of {blocks * (n // hop)} columns x {C} channel(s), dB ring on the device",
+            "host_memory": out, "note": "PCIe-inclusive: the H2D copy of the samples is inside the timed loop; never the `value`"}
+
+
 def parity_report(jsg, c, plan, d_in_host, win):
     """What the tolerances of the parity tests mean on THIS workload (rank 0, N = 1), measured on the launch geometry of the timed
     region -- the same frame count, channel count and automatic kernel selection, so the numbers describe the kernel that is
@@ -234,6 +286,7 @@ def main():
     ap.add_argument("--issue-threads", type=int, default=2, help="host threads issuing the launches of a step (c2, streams > 1)")
     ap.add_argument("--blocks-per-cu", type=int, default=1, help="workgroups per CU of each launch when launches overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the `boundary` block (jsg_process_block latency, PCIe-inclusive rate)")
     ap.add_argument("--gate", action="store_true", help="with --no-graph: hold the stream with a gate kernel while the host enqueues a step's "
                                                         "launches, so that they run back to back even under a tracer (short kernels: c2)")
     ap.add_argument("--no-graph", action="store_true", help="issue the in-order launches from the host instead of replaying a hipGraph "
@@ -255,6 +308,9 @@ def main():
     if not args.dry_run and not args.no_cpu_baseline and world == 1:   # the CPU baseline leg runs at N = 1 only
         from oracle import oracle_c
         oracle_c.load()
+    boundary = None
+    if not args.dry_run and not args.no_boundary and world == 1:
+        boundary = {"process_block_latency": boundary_latency_subprocess()}
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1:
@@ -323,6 +379,12 @@ def main():
                 d_out.append(torch.empty((F, pitch), dtype=torch.float32, device="cuda"))
         d_lut = torch.from_numpy(jsg.colormap_lut(256, jsg.capi.CM_JADE)).cuda() if c["colour"] else None
         fb = n // hop
+        kernel_label = None
+        if c["colour"]:
+            two = jsg.stft_image_needs_scratch(plan, d_in[0], hop, F, d_lut, -50.0, 50.0, d_img[0][:, :F], d_scr[0], feedblocks=fb,
+                                               mix_mode=jsg.capi.MIX_ABSMEAN)
+            kernel_label = ("stft_db_kernel<4096, AbsMean, index out> + colormap_kernel (jsg_stft_image_launch, two kernels)" if two else
+                            "stft_db_kernel<Cfg4096B, AbsMean, ARGB out> (jsg_stft_image_launch, one kernel: the workgroup colours its columns)")
         one = torch.cuda.Stream()
 
         def launch(b, stream_handle, bpc=0):
@@ -558,8 +620,7 @@ def main():
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "frac_of_8p0": achieved / HBM_PEAK_GBS, "frac_of_6p3": achieved / HBM_ACHIEVABLE_GBS,
             "traffic": traffic, "traffic_source": tsrc,
-            "kernel": ("stft_db_kernel<4096, AbsMean, index out> + colormap_kernel (jsg_stft_image_launch)" if c["colour"]
-                       else f"stft_db_kernel<{n}>"),
+            "kernel": (kernel_label if c["colour"] else f"stft_db_kernel<{(parity or {}).get('kernel', n)}>"),
             "avg_launch_us": inorder_us, "avg_launch_us_host_issued": eager_us,
             "how": f"HIP events on the launch stream around {'host-issued runs' if args.no_graph else 'hipGraph replays'} of the step's {lps} launches, one at a time in order",
             "algorithmic_bytes_per_launch": algo,
@@ -571,6 +632,9 @@ def main():
         }
     if parity is not None:
         out["parity"] = parity
+    if boundary is not None and rank == 0:
+        boundary["pcie_inclusive_rate"] = boundary_pcie_rate(jsg, c)
+        out["boundary"] = boundary
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             out["cpu_baseline"] = cpu_baseline(c)

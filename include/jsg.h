@@ -136,11 +136,14 @@ typedef struct jsg_stft_args {
     int64_t in_samples;      /* floats of every channel row that may be read; the launch is refused (JSG_ERR_INVALID) when
                                 its last frame would read past them.  0: unknown, not checked */
     int32_t plan_select;     /* 2048 / 4096 points have two kernels each.  0: automatic -- the large-workgroup "B" kernel (one 8-wave
-                                workgroup of 16 / 8 columns per CU; faster when it can fill the GPU) for launches that mix >= 3
-                                channels per column AND fill their rounds of 256 workgroups to at least 87 % (e.g. 3584..4096
-                                columns of 2048 points, or any launch of 7 rounds and more), the small-workgroup kernel otherwise.  1: always the small-workgroup kernel, 2: always "B".  The two round differently in
+                                workgroup of 16 / 8 columns per CU; faster when it can fill the GPU) for launches that fill their
+                                rounds of <CU count> workgroups to at least 87 % (e.g. 3584..4096 columns of 2048 points or
+                                1784..2048 of 4096 points on 256 CUs, or any launch of 7 rounds and more) AND, at 2048 points, mix
+                                >= 3 channels per column (at 4096 points "B" is ahead at every channel count); the small-workgroup
+                                kernel otherwise.  1: always the small-workgroup kernel, 2: always "B".  The two round differently in
                                 the last bits (both inside the parity bound): callers that cut one stream into launches of
-                                very different sizes and need bit-identical columns pin one of them.  Other sizes: ignored */
+                                very different sizes and need bit-identical columns pin one of them (the engine pins 1).
+                                jsg_stft_kernel_name() tells which one a launch takes.  Other sizes: ignored */
     int32_t reserved;        /* 0 */
 } jsg_stft_args;
 int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* args, void* stream);
@@ -202,19 +205,25 @@ typedef struct jsg_colormap_args {
 int jsg_colormap_launch(const jsg_colormap_args* args, void* stream);
 
 /* Fused display path: STFT -> palette index -> ARGB without the dB column ever going to memory (reference
- * Spectrogram.cpp:632-648: the colour loop consumes the column the engine has just produced).  Two kernels on `stream`:
- * the STFT kernel with an epilogue that writes 1 byte per bin (CColorPalette::getRGBColor's index, CColorpalette.h:34-45)
- * into `index_scratch`, and the colour kernel reading those bytes.  The image is bit-identical to jsg_stft_db_launch
- * followed by jsg_colormap_launch.  stft.out_db may be NULL (it is not written); colour.db is ignored; colour must
- * cover exactly the columns of the launch (n_cols == n_frames, col_first == ring_pos, ring_width equal, height n/2+1);
- * n_colors <= 256; mixes: AbsMean / Sum / Left / Right. */
+ * Spectrogram.cpp:632-648: the colour loop consumes the column the engine has just produced).  The image is bit-identical to
+ * jsg_stft_db_launch (same plan_select) followed by jsg_colormap_launch.
+ *   ONE kernel where a workgroup of the plan holds eight whole columns -- 1024 points, and 4096 points when the launch takes the
+ *   one-wavefront-per-frame kernel (automatic rule of jsg_stft_args.plan_select, or plan_select = 2; e.g. a 10-second stereo image
+ *   at 96 kHz = 1875 columns): the workgroup parks the palette indices (CColorPalette::getRGBColor's index, CColorpalette.h:34-45)
+ *   of its columns in LDS and writes the ARGB rows itself; only the input is read, only the image is written, `index_scratch`
+ *   is not touched and may be NULL.  Needs colour.argb_out, no colour.index_out, n_colors <= 256, n_cols <= x_wrap.
+ *   TWO kernels otherwise: the STFT kernel writes 1 byte per bin into `index_scratch`, the colour kernel reads those bytes.
+ * jsg_stft_image_needs_scratch() tells which (1: index_scratch is required, 0: it is not used).
+ * stft.out_db may be NULL (it is not written); colour.db is ignored; colour must cover exactly the columns of the launch
+ * (n_cols == n_frames, col_first == ring_pos, ring_width equal, height n/2+1); n_colors <= 256; mixes: AbsMean / Sum / Left / Right. */
 typedef struct jsg_stft_image_args {
     jsg_stft_args stft;
     jsg_colormap_args colour;
-    uint8_t* index_scratch;        /* device: ring_width columns of index_scratch_pitch bytes each */
+    uint8_t* index_scratch;        /* device: ring_width columns of index_scratch_pitch bytes each (two-kernel form only) */
     int64_t index_scratch_pitch;   /* >= n/2+1; a multiple of 64 keeps the columns line-aligned */
 } jsg_stft_image_args;
 int jsg_stft_image_launch(const jsg_plan* plan, const jsg_stft_image_args* args, void* stream);
+int jsg_stft_image_needs_scratch(const jsg_plan* plan, const jsg_stft_image_args* args);
 
 /* ------------------------------------------------------------------------------------------------
  * 3. Engine: the state of class Spectrogram (Spectrogram.h:81-169) living on the GPU.

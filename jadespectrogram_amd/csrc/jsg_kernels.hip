@@ -286,7 +286,9 @@ using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, JSG_X_WPB2048, 1, JSG_X_W
 // The launcher picks by channel count and by how well the launch fills its rounds (stft_launch_impl).
 using Cfg2048B = Cfg<2048, 32, 32, 1, 32, 34, 0, 0, 0, 8, 1, 1>;
 constexpr int k2048B_min_channels = 3;   // channels mixed into one column from which the two-stage plan is the faster one
-constexpr int k4096B_min_channels = 3;   // ... and the one-wavefront-per-frame 4096-point plan
+constexpr int k4096B_min_channels = 1;   // ... the one-wavefront-per-frame 4096-point plan is ahead at every channel count once the rounds are
+                                         // full (round 3, 16 384 FFTs, inputs and rings rotating over 1 GB: mono 66.5 vs 73.4 us, stereo 56.7 vs 60.8,
+                                         // 4 ch 51.6 vs 57.6, 8 ch 50.3 vs 54.7); launches that do not fill their rounds keep the two-wave plan
 // The "B" plans run ONE 8-wave workgroup per CU (16 / 8 frames at a time), i.e. a launch proceeds in rounds of <CU count> workgroups:
 // a launch that fills its last round badly leaves CUs idle where the small workgroups of the other plan would fill them
 // (1024 stereo 2048-point frames: 7.2 vs 13.0 us).  At full rounds "B" is about 13 % faster, so it is used when the rounds of
@@ -363,6 +365,11 @@ struct StftKArgs {
     long long idx_pitch;          // bytes between index columns
     float vmin, vmax, top, mult;  // CColorPalette::setValueRange / getRGBColor (CColorpalette.cpp:39-54, CColorpalette.h:34-45)
     int n_colors;
+    // OUTK == 2 (single-kernel display path): the workgroup turns the columns of an iteration into ARGB image rows itself
+    unsigned* argb;               // image [height][argb_pitch], pixel (x, height - 1 - bin)
+    long long argb_pitch;
+    const int* lut;               // n_colors entries 0x00RRGGBB
+    int x_first, x_wrap;          // column i of the launch lands at x = (x_first + i) % x_wrap
 };
 
 // dB = 10*log10(p + 1e-11f) -- reference Spectrogram.cpp:107 with g_minValForLogSpectrogram (:36).
@@ -416,7 +423,11 @@ __device__ __forceinline__ cf mix_combine2(cf acc, cf pw) {
 #define JSG_NO_LDS_MERGE
 #endif
 // OUTK: 0 = the column is stored as floats (dB, or linear power), 1 = as 8-bit palette indices (fused display path:
-// the dB value never goes to memory; reference Spectrogram.cpp:632-648 consumes the column it has just produced).
+// the dB value never goes to memory; reference Spectrogram.cpp:632-648 consumes the column it has just produced),
+// 2 = the workgroup colours its columns itself (one-wavefront-per-frame plans): the palette indices of the TPB consecutive
+// columns of an iteration are parked in the (then idle) exchange regions, and after a workgroup barrier all waves write
+// ARGB image rows -- runs of TPB pixels (32 bytes for the eight-frame workgroups) per row.  Neither the dB column nor an index
+// column goes to memory: per C5 column 4096 B in + 8196 B out, the algorithmic bytes.
 template <class C, int MIXOP, int OUTK = 0>
 __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_kernel(
     // Everything the table and frame loads depend on sits in the first 16 dwords of the kernel arguments: with
@@ -435,6 +446,8 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     // Two distinct LDS objects on purpose: the (read-only) lane tables and the exchange buffers.  With one object
     // the compiler must assume that a table read may alias an exchange store and serialises them.
     __shared__ __attribute__((aligned(16))) cf s_tab[C::TLOC == 1 ? C::TAB_ELEMS : 2];
+    __shared__ int s_lut[OUTK == 2 ? 256 : 1];
+    static_assert(OUTK != 2 || (C::L == 64 && C::FPW == 1 && C::LDS_TOTAL + 1024 <= 160 * 1024), "single-kernel display path: one wavefront per frame");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int L = C::L, P = C::P, M = C::M, R1 = C::R1, R2 = C::R2, R3 = C::R3, F = C::FPW;
     constexpr int U1 = C::U1, U2 = C::U2, U3 = C::U3;
@@ -532,6 +545,9 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         tBase = s_tab;
     } else {
         tBase = reinterpret_cast<const cf*>(a.tab);
+    }
+    if constexpr (OUTK == 2) {   // colour table into LDS (n_colors <= 256); it is read after the first workgroup barrier of the store phase
+        if (threadIdx.x < 256) s_lut[threadIdx.x] = a.lut[(int)threadIdx.x < a.n_colors ? (int)threadIdx.x : a.n_colors - 1];
     }
     cf twA[C::TWF ? U2 : 1], twC = {0.f, 0.f};           // TWF: this lane's constant factors (see Cfg)
     int twBrow = 0;
@@ -712,8 +728,25 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         for (int f = 0; f < F; ++f)
 #pragma unroll
             for (int w = 0; w < U3; ++w) {
+                if constexpr (C::AZ == 1) {
+                    // AZ == 1 (512 points, 4096 "B"): the n3 values of a lane are neighbours, and the IR load/store vectorizer
+                    // (not the backend pass that JSG_NO_LDS_MERGE switches off) pairs them into 16-byte loads of 8-byte
+                    // alignment = ds_read2_b64: 8 LDS cycles instead of 2 x 2, banked differently from what the layout was
+                    // searched for (profile of round 3: 15.7 % of the LDS cycles of the 4096 "B" kernel were bank conflicts).
+                    // The odd n3 are therefore read through a second pointer whose relation to the first the optimizer cannot see.
+                    typedef const cf __attribute__((address_space(3))) * lds_cf_ptr;   // (an LDS pointer: 32 bits, stays a ds_read)
+                    const lds_cf_ptr pe = (lds_cf_ptr)(lds0 + f * C::LDS_ELEMS + e2r[w]);
+                    lds_cf_ptr po = pe + 1;
+                    asm("" : "+v"(po));
 #pragma unroll
-                for (int n3 = 0; n3 < R3; ++n3) x[f][w * R3 + n3] = lds0[f * C::LDS_ELEMS + e2r[w] + n3 * C::AZ];
+                    for (int n3 = 0; n3 < R3; n3 += 2) {
+                        x[f][w * R3 + n3] = pe[n3];
+                        x[f][w * R3 + n3 + 1] = po[n3];
+                    }
+                } else {
+#pragma unroll
+                    for (int n3 = 0; n3 < R3; ++n3) x[f][w * R3 + n3] = lds0[f * C::LDS_ELEMS + e2r[w] + n3 * C::AZ];
+                }
             }
         frame_sync();
 #pragma unroll
@@ -845,7 +878,62 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                 const unsigned colB = L == 32 ? (unsigned)__builtin_amdgcn_readlane((int)col, 32) : col;
                 constexpr int LW = L == 32 ? 64 : L;         // lanes that share one store instruction's run
                 const int lw = L == 32 ? lane : ll;
-                if constexpr (OUTK == 1) {
+                if constexpr (OUTK == 2) {
+                    // palette indices of the column, four to a dword, into this wave's exchange region: dword (r4, ll) of the lower
+                    // half holds bins ll + 64 (4 r4 + j), j = 0..3, the upper half M - those; the region is skewed per wave so that
+                    // the store phase below reads without bank conflicts (eight columns x eight consecutive ll per instruction)
+                    constexpr int D = C::LDS_ELEMS * 2;                       // dwords between the waves' regions
+                    constexpr int SK = ((4 - D % 32) + 32) % 32;              // skew per wave: (D + SK) == 4 (mod 32)
+                    unsigned* ix = reinterpret_cast<unsigned*>(lds0 + f * C::LDS_ELEMS) + (SK * wave) % 32;
+#pragma unroll
+                    for (int r4 = 0; r4 < P / 8; ++r4) {
+                        unsigned wx = 0, wy = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            wx |= (unsigned)color_index(acc[f][4 * r4 + j].x, a.vmin, a.vmax, a.top, a.mult, a.n_colors) << (8 * j);
+                            wy |= (unsigned)color_index(acc[f][4 * r4 + j].y, a.vmin, a.vmax, a.top, a.mult, a.n_colors) << (8 * j);
+                        }
+                        ix[r4 * 64 + ll] = wx;
+                        ix[(P / 8 + r4) * 64 + ll] = wy;
+                    }
+                    if (ll == 0) ix[(P / 4) * 64] = (unsigned)color_index(accNy[f], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
+                    __syncthreads();
+                    {
+                        // ---- store phase: every wave-instruction covers 8 consecutive values of ll (rows) x the 8 columns of the
+                        //      iteration: lane = 8 * dl + c reads dword (h, r4, 8 g + dl) of column c and writes four pixels ----
+                        const int c = lane & 7, dl = lane >> 3;
+                        static_assert(C::TPB == 8 && C::WPB == 8, "the store phase is laid out for eight columns per iteration");
+                        const unsigned tcol = task0 - slot0 + it * task_stride + c;   // column c of this iteration (task0 holds this wave's slot)
+                        const bool live = tcol < a.n_frames;
+                        const unsigned* cx = reinterpret_cast<const unsigned*>(smem_raw) + c * D + (SK * c) % 32;
+                        unsigned x = (unsigned)a.x_first + tcol;
+                        x %= (unsigned)a.x_wrap;
+                        unsigned* const img = a.argb + x;
+                        constexpr int ITEMS = 2 * (P / 8) * 8;               // (half, r4, group of eight ll)
+                        for (int q = wave; q < ITEMS; q += C::WPB) {
+                            const int g = q & 7, hr = q >> 3;                // hr = h * (P / 8) + r4
+                            const int r4 = hr % (P / 8);
+                            const bool upper = hr >= P / 8;
+                            const unsigned w4 = cx[hr * 64 + 8 * g + dl];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int k = 8 * g + dl + 64 * (4 * r4 + j);
+                                const int bin = upper ? M - k : k;
+                                const int rgb = s_lut[(w4 >> (8 * j)) & 0xffu];
+                                // y = H - 1 - bin (Spectrogram.cpp:642).  Plain stores on purpose: a wave-instruction writes 32-byte pieces of eight
+                                // image rows, and the neighbouring workgroups (same XCD: the block remap gives an XCD one contiguous column
+                                // range) write the rest of those 128-byte lines; with the default policy the pieces meet in L2 and leave as
+                                // whole lines, streamed out (non-temporal) every piece went to memory alone: 28.6 vs 22.3 us per C5 image
+                                if (live) img[(long long)(M - bin) * a.argb_pitch] = (unsigned)rgb | 0xFF000000u;
+                            }
+                        }
+                        if (wave == C::WPB - 1 && dl == 0 && live) {     // bin M / 2 of the eight columns
+                            const int rgb = s_lut[cx[(P / 4) * 64] & 0xffu];
+                            img[(long long)(M - M / 2) * a.argb_pitch] = (unsigned)rgb | 0xFF000000u;
+                        }
+                    }
+                    __syncthreads();   // the next round's exchange stores stay behind the reads of the store phase
+                } else if constexpr (OUTK == 1) {
                     // palette index of every bin; 64 consecutive bytes of the index column per store instruction
                     unsigned char* icA = a.idx + (long long)colA * a.idx_pitch;
                     unsigned char* icB = a.idx + (long long)colB * a.idx_pitch;
@@ -1065,6 +1153,10 @@ static hipError_t ensure_lds_attr() {
     return hipSuccess;
 }
 
+// plans that can colour their own columns (stft_db_kernel, OUTK == 2): one wavefront per frame, eight frames per workgroup
+template <class C>
+constexpr bool image_ok = C::L == 64 && C::FPW == 1 && C::TPB == 8 && C::WPB == 8 && C::LDS_TOTAL + 1024 <= 160 * 1024;
+
 template <class C>
 static hipError_t ensure_lds_attrs_of_plan() {
     hipError_t e = ensure_lds_attr<C, 0, 0>();
@@ -1073,6 +1165,10 @@ static hipError_t ensure_lds_attrs_of_plan() {
     if (e == hipSuccess) e = ensure_lds_attr<C, 3, 0>();
     if (e == hipSuccess) e = ensure_lds_attr<C, 0, 1>();
     if (e == hipSuccess) e = ensure_lds_attr<C, 3, 1>();
+    if constexpr (image_ok<C>) {
+        if (e == hipSuccess) e = ensure_lds_attr<C, 0, 2>();
+        if (e == hipSuccess) e = ensure_lds_attr<C, 3, 2>();
+    }
     return e;
 }
 
@@ -1088,6 +1184,13 @@ static hipError_t launch_stft_mix(const StftKArgs& ka, dim3 grid, hipStream_t s)
 
 template <class C>
 static hipError_t launch_stft(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s) {
+    if (ka.argb) {  // single-kernel display path
+        if constexpr (image_ok<C>) {
+            if (mixop == 3) return launch_stft_mix<C, 3, 2>(ka, grid, s);
+            if (mixop == 0) return launch_stft_mix<C, 0, 2>(ka, grid, s);
+        }
+        return hipErrorInvalidValue;
+    }
     if (ka.idx) {   // fused display path: the mixed (AbsMean / Sum) and the one-channel instantiations only
         if (mixop == 3) return launch_stft_mix<C, 3, 1>(ka, grid, s);
         if (mixop == 0) return launch_stft_mix<C, 0, 1>(ka, grid, s);
@@ -1280,11 +1383,16 @@ int jsg_plan_fft_size(const jsg_plan* plan) { return plan ? plan->n : JSG_ERR_IN
 }   // extern "C"
 
 namespace {
-struct IndexOut {   // fused display path: where and how the palette indices of the columns are written
+struct IndexOut {   // fused display path: where and how the palette indices of the columns are written ...
     unsigned char* idx;
     long long pitch;
     float vmin, vmax, mult;
     int n_colors;
+    // ... or (single-kernel path, idx == nullptr) where the ARGB pixels go
+    unsigned* argb;
+    long long argb_pitch;
+    const int* lut;
+    int x_first, x_wrap;
 };
 }  // namespace
 
@@ -1307,8 +1415,11 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
         g->first_frame < 0 || g->ring_width <= 0 || g->ring_pos < 0 || g->ring_pos >= g->ring_width ||
         (!io && g->out_pitch < H))
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: bad geometry");
-    if (io && (!io->idx || io->pitch < H || io->n_colors <= 0 || io->n_colors > 256 || g->linear_out))
+    if (io && !io->argb && (!io->idx || io->pitch < H || io->n_colors <= 0 || io->n_colors > 256 || g->linear_out))
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch: bad index scratch (needs n_colors <= 256, pitch >= n/2+1, dB mode)");
+    if (io && io->argb && (!io->lut || io->n_colors <= 0 || io->n_colors > 256 || io->x_wrap <= 0 || io->x_first < 0 || g->linear_out ||
+                           (plan->n != 1024 && plan->n != 4096)))
+        return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch: bad image geometry for the single-kernel path");
     if (g->n_frames > g->ring_width)
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: more frames than ring columns in one launch (columns would race)");
     int dev = -1;
@@ -1341,6 +1452,11 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     ka.tab = plan->d_tab;
     ka.stamps = g_dev_stamps;
     if (io) {
+        ka.argb = io->argb;
+        ka.argb_pitch = io->argb_pitch;
+        ka.lut = io->lut;
+        ka.x_first = io->x_first;
+        ka.x_wrap = io->x_wrap;
         ka.idx = io->idx;
         ka.idx_pitch = io->pitch;
         ka.vmin = io->vmin;
@@ -1391,7 +1507,8 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     // launch fills its rounds, else the other one (see Cfg2048B, Cfg4096B, kB_min_round_fill).  The choice depends on the launch
     // geometry (channels per column, frames, CU count) only; sub-launches of one stream that fall on different sides of the rule
     // agree within the float32 bound, not bit for bit (jsg.h: plan_select pins one plan).
-    const bool plan_b = wants_plan_b(plan->n, g, ka.per_channel ? 1 : ka.c_end - ka.c_begin, n_cu);
+    // (the single-kernel display path exists for the one-wavefront-per-frame plans: at 4096 points that is "B")
+    const bool plan_b = (io && io->argb && plan->n == 4096) || wants_plan_b(plan->n, g, ka.per_channel ? 1 : ka.c_end - ka.c_begin, n_cu);
     if (plan_b) ka.tab = plan->d_tab_b;
     int tpb = 0;
     switch (plan->n) {
@@ -1457,6 +1574,31 @@ static int colormap_launch_impl(const jsg_colormap_args* g, const unsigned char*
 // into `index_scratch` -- the dB column never goes to memory -- and the colour kernel turns those columns into ARGB
 // image rows through its LDS transpose tiles.  Per column of C5: 4096 B in + 2049 B + 2049 B + 8196 B instead of
 // 4096 + 8196 + 8196 + 8196 B.  The image is bit-identical to jsg_stft_db_launch + jsg_colormap_launch.
+// Does jsg_stft_image_launch run as ONE kernel for these arguments?  Where the plan's workgroups hold eight whole columns: 1024
+// points, and 4096 points when the launcher's choice for the launch is the one-wavefront-per-frame kernel ("B": automatic rule or
+// plan_select = 2) -- so the image is always that of jsg_stft_db_launch (same plan_select) + jsg_colormap_launch, bit for bit.
+static bool image_takes_one_kernel(const jsg_plan* plan, const jsg_stft_image_args* g) {
+    static const int two_kernels = getenv("JSG_IMAGE_TWO_KERNELS") ? 1 : 0;   // development A/B
+    const jsg_colormap_args& c = g->colour;
+    if (two_kernels || !(plan->n == 1024 || plan->n == 4096) || !c.argb_out || c.index_out || c.n_colors <= 0 || c.n_colors > 256 ||
+        !c.lut || c.x_wrap <= 0 || c.x_first < 0 || c.n_cols > c.x_wrap)
+        return false;
+    const int mm = g->stft.mix_mode;
+    if (mm == JSG_MIX_PER_CHANNEL || mm == JSG_MIX_MAX || mm == JSG_MIX_MIN) return false;
+    if (plan->n == 4096) {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        const int nc = (mm == JSG_MIX_LEFT || mm == JSG_MIX_RIGHT) ? 1 : g->stft.channels;
+        return wants_plan_b(4096, &g->stft, nc, cu_count_of_device(dev));
+    }
+    return true;
+}
+
+int jsg_stft_image_needs_scratch(const jsg_plan* plan, const jsg_stft_image_args* g) {
+    if (!plan || !g) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_needs_scratch: null argument");
+    return image_takes_one_kernel(plan, g) ? 0 : 1;
+}
+
 int jsg_stft_image_launch(const jsg_plan* plan, const jsg_stft_image_args* g, void* stream) {
     if (!plan || !g) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch: null argument");
     if (g->stft.n_frames == 0) return JSG_OK;
@@ -1466,7 +1608,18 @@ int jsg_stft_image_launch(const jsg_plan* plan, const jsg_stft_image_args* g, vo
     if (c.n_cols != g->stft.n_frames || c.ring_width != g->stft.ring_width || c.height != plan->n / 2 + 1 ||
         (c.col_first % c.ring_width) != g->stft.ring_pos)
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch: the colour loop must cover exactly the columns of the launch");
-    IndexOut io{g->index_scratch, (long long)g->index_scratch_pitch, c.vmin, c.vmax, c.access_mult, c.n_colors};
+    // Single kernel where the plan's workgroups hold eight whole columns (1024 points; 4096 points: the one-wavefront-per-frame
+    // kernel): the workgroup colours its columns itself and writes ARGB rows -- nothing but the input is read, nothing but the
+    // image is written.  Everything else: index columns through `index_scratch` + the colour kernel.
+    const bool single = image_takes_one_kernel(plan, g);
+    if (!single && !g->index_scratch)
+        return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch: this launch needs index_scratch (jsg_stft_image_needs_scratch)");
+    if (single) {
+        IndexOut io{nullptr, 0, c.vmin, c.vmax, c.access_mult, c.n_colors, c.argb_out, (long long)c.argb_pitch, c.lut,
+                    c.x_first % c.x_wrap, c.x_wrap};
+        return stft_launch_impl(plan, &g->stft, &io, stream);
+    }
+    IndexOut io{g->index_scratch, (long long)g->index_scratch_pitch, c.vmin, c.vmax, c.access_mult, c.n_colors, nullptr, 0, nullptr, 0, 1};
     int rc = stft_launch_impl(plan, &g->stft, &io, stream);
     if (rc != JSG_OK) return rc;
     return colormap_launch_impl(&c, g->index_scratch, (long long)g->index_scratch_pitch, stream);

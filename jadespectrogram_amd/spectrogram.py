@@ -340,18 +340,15 @@ def colormap(d_db, d_lut, lo: float, hi: float, *, d_argb=None, d_index=None, co
     check(lib().jsg_colormap_launch(C.byref(a), C.c_void_p(stream)))
 
 
-def stft_image(plan: Plan, d_in, hop: int, n_frames: int, d_lut, lo: float, hi: float, d_argb, d_index_scratch, *,
-               feedblocks: int | None = None, mix_mode: int = 0, first_frame: int = 0, ring_pos: int = 0, ring_width: int | None = None,
-               x_first: int | None = None, stream: int | None = None, plan_select: int = 0):
-    """Fused display path (jsg_stft_image_launch): STFT -> 8-bit palette index columns (d_index_scratch, uint8
-    [ring_width][pitch >= n/2+1]) -> ARGB rows of d_argb [n/2+1][Wimg]; no dB column is written.  The image equals
-    stft_db() + colormap() bit for bit."""
+def _stft_image_args(plan: Plan, d_in, hop: int, n_frames: int, d_lut, lo: float, hi: float, d_argb, d_index_scratch, *,
+                     feedblocks: int | None = None, mix_mode: int = 0, first_frame: int = 0, ring_pos: int = 0,
+                     ring_width: int | None = None, x_first: int | None = None, plan_select: int = 0):
     import torch
-    assert d_index_scratch.is_cuda and d_index_scratch.dtype == torch.uint8 and d_index_scratch.dim() == 2 and d_index_scratch.stride(1) == 1
     assert d_argb.is_cuda and d_argb.element_size() == 4 and d_argb.dim() == 2 and d_argb.stride(1) == 1
-    W = ring_width if ring_width is not None else d_index_scratch.shape[0]
+    if d_index_scratch is not None:
+        assert d_index_scratch.is_cuda and d_index_scratch.dtype == torch.uint8 and d_index_scratch.dim() == 2 and d_index_scratch.stride(1) == 1
+    W = ring_width if ring_width is not None else (d_index_scratch.shape[0] if d_index_scratch is not None else n_frames)
     a = capi.StftImageArgs()
-    dummy = torch.empty((W, 0), dtype=torch.float32, device=d_in.device)   # geometry only: out_db stays NULL
     H = plan.n // 2 + 1
     st = capi.StftArgs()
     st.in_ = d_in.data_ptr()
@@ -366,7 +363,6 @@ def stft_image(plan: Plan, d_in, hop: int, n_frames: int, d_lut, lo: float, hi: 
     st.ring_width = W
     st.ring_pos = ring_pos
     st.plan_select = int(plan_select)
-    del dummy
     a.stft = st
     c = capi.ColormapArgs()
     c.ring_width = W
@@ -381,11 +377,29 @@ def stft_image(plan: Plan, d_in, hop: int, n_frames: int, d_lut, lo: float, hi: 
     c.argb_out = d_argb.data_ptr()
     c.argb_pitch = d_argb.stride(0)
     a.colour = c
-    a.index_scratch = d_index_scratch.data_ptr()
-    a.index_scratch_pitch = d_index_scratch.stride(0)
+    if d_index_scratch is not None:
+        a.index_scratch = d_index_scratch.data_ptr()
+        a.index_scratch_pitch = d_index_scratch.stride(0)
+    return a
+
+
+def stft_image(plan: Plan, d_in, hop: int, n_frames: int, d_lut, lo: float, hi: float, d_argb, d_index_scratch=None, *,
+               stream: int | None = None, **kw):
+    """Fused display path (jsg_stft_image_launch): STFT -> palette index -> ARGB rows of d_argb [n/2+1][Wimg]; no dB column is
+    written.  One kernel where the plan's workgroups hold eight whole columns (1024 points; 4096 points when the launch takes
+    the "B" kernel), else two kernels through d_index_scratch (uint8 [ring_width][pitch >= n/2+1]; stft_image_needs_scratch()).
+    The image equals stft_db() + colormap() bit for bit."""
+    import torch
+    a = _stft_image_args(plan, d_in, hop, n_frames, d_lut, lo, hi, d_argb, d_index_scratch, **kw)
     if stream is None:
         stream = torch.cuda.current_stream(d_in.device).cuda_stream
     check(lib().jsg_stft_image_launch(plan._p, C.byref(a), C.c_void_p(stream)))
+
+
+def stft_image_needs_scratch(plan: Plan, d_in, hop: int, n_frames: int, d_lut, lo: float, hi: float, d_argb, d_index_scratch=None, **kw) -> bool:
+    """True when jsg_stft_image_launch runs as two kernels for this launch and therefore needs the index scratch."""
+    a = _stft_image_args(plan, d_in, hop, n_frames, d_lut, lo, hi, d_argb, d_index_scratch, **kw)
+    return bool(check(lib().jsg_stft_image_needs_scratch(plan._p, C.byref(a))))
 
 
 def db_from_power(d_power, d_out, divisor: float = 1.0, stream: int | None = None):

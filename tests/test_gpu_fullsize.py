@@ -193,7 +193,22 @@ def test_c5_fused_image_equals_two_kernel_image(jsg, oracle, torch_cuda):
     jsg.stft_image(plan, d_in, hop, F, d_lut, -50.0, 50.0, fused[:, :F], scratch, feedblocks=8, ring_pos=pos)
     torch.cuda.synchronize()
     assert torch.equal(fused, two)
-    # and the scratch holds exactly the oracle's palette index of the GPU's own dB values
+    # 1875 stereo columns fill their round of workgroups: the launch takes the one-wavefront-per-frame kernel and colours its
+    # columns itself -- ONE kernel, the scratch is not touched (and need not exist)
+    assert jsg.stft_kernel_name(plan, d_in, hop, F, d_db, feedblocks=8) == "Cfg4096B"
+    assert not jsg.stft_image_needs_scratch(plan, d_in, hop, F, d_lut, -50.0, 50.0, fused[:, :F], None, feedblocks=8, ring_pos=pos, ring_width=F)
+    assert not scratch.any()
+    fused2 = torch.zeros_like(two)
+    jsg.stft_image(plan, d_in, hop, F, d_lut, -50.0, 50.0, fused2[:, :F], None, feedblocks=8, ring_pos=pos, ring_width=F)
+    # pinned to the two-wave kernel the same launch goes through the index scratch (two kernels): the scratch then holds exactly
+    # the oracle's palette index of the GPU's own dB values, and the image is that of stft_db(plan_select=1) + colormap
+    two1, fused1 = torch.zeros_like(two), torch.zeros_like(two)
+    jsg.stft_db(plan, d_in, hop, F, d_db, feedblocks=8, ring_pos=pos, plan_select=1)
+    jsg.colormap(d_db, d_lut, -50.0, 50.0, d_argb=two1[:, :F], col_first=pos, x_first=pos, height=H)
+    assert jsg.stft_image_needs_scratch(plan, d_in, hop, F, d_lut, -50.0, 50.0, fused1[:, :F], scratch, feedblocks=8, ring_pos=pos, plan_select=1)
+    jsg.stft_image(plan, d_in, hop, F, d_lut, -50.0, 50.0, fused1[:, :F], scratch, feedblocks=8, ring_pos=pos, plan_select=1)
+    torch.cuda.synchronize()
+    assert torch.equal(fused2, two) and torch.equal(fused1, two1)
     pal = oracle.OracleColorPalette(256, oracle.CM_JADE); pal.set_value_range(-50.0, 50.0)
     assert (scratch[:, :H].cpu().numpy() == pal.index(d_db[:, :H].cpu().numpy()).astype(np.uint8)).all()
 
@@ -236,9 +251,9 @@ def test_persistent_loop_of_every_plan(jsg, oracle, torch_cuda, n, F, C):
     d_a = torch.empty((F, pitch), device="cuda")
     d_b = torch.empty((F, pitch), device="cuda")
     fb = n // hop
-    # >= 3 channels at 2048 / 4096 points: the automatic kernel choice looks at how well a launch fills its rounds, which
-    # differs between the whole and the halves -- bit-identical sub-launches are what plan_select is for
-    sel = 2 if (C >= 3 and n in (2048, 4096)) else 0
+    # 4096 points (any channel count) and >= 3 channels at 2048 points: the automatic kernel choice looks at how well a launch
+    # fills its rounds, which differs between the whole and the halves -- bit-identical sub-launches are what plan_select is for
+    sel = 2 if (n == 4096 or (C >= 3 and n == 2048)) else 0
     jsg.stft_db(plan, d_in, hop, F, d_a, feedblocks=fb, plan_select=sel)
     half = F // 2 + 3
     jsg.stft_db(plan, d_in, hop, half, d_b, feedblocks=fb, plan_select=sel)
@@ -383,3 +398,35 @@ def test_grid_shape_ring_position_and_ring_alignment_do_not_change_the_bits(jsg,
             assert torch.equal(odd[:, :H], ref[:, :H]), (n, hop, F, "odd")
     frames = sorted(np.random.default_rng(7).choice(F, 16, replace=False).tolist())
     _spot_check(oracle, d_in, ref[frames][:, :H].cpu().numpy(), n, hop, win, frames)
+
+
+@pytest.mark.parametrize("cfg,kernel,max_share_beyond_1e5", [("c2", "Cfg1024", 0.01), ("c3", "Cfg2048B", 0.0), ("c5", "Cfg4096B", 0.002)])
+def test_baseline_config_accuracy_contract(jsg, oracle, torch_cuda, cfg, kernel, max_share_beyond_1e5):
+    """The accuracy contract of DESIGN.md section 2 as regression guards, on the BASELINE configurations at their full launch
+    size and with the kernel the benchmark times (bench.parity_report is the code that fills the bench line's "parity" block):
+      * share of bins whose relative power error against the float64 DFT exceeds plain 1e-5: C2 <= 1 %, C3 = 0, C5 <= 0.2 %
+        (all of them far below their frame's peak), and plain 5e-6 on every bin within 20 dB of the peak;
+      * error relative to the frame peak <= FLOOR(n) (tests/parity_util.py);
+      * colour indices end to end (GPU power -> dB -> index against oracle power -> dB -> index): at most 1 per 50 000 pixels;
+      * the fused image equals the two-kernel image.
+    Reference: Spectrogram.cpp:107 (dB), CColorpalette.h:32-47 (index)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from parity_util import STRONG_REL, floor_for
+    c = bench.CONFIGS[cfg]
+    n, hop, C, F = c["n"], c["hop"], c["channels"], c["frames"]
+    win = jsg.window(jsg.capi.WIN_HANN, n)
+    plan = jsg.Plan(n, win)
+    base = bench.synth_audio(C, F * hop + (n - hop), fs=c["fs"], seed=1234)
+    rep = bench.parity_report(jsg, c, plan, base, win)
+    print(cfg, rep)
+    assert rep["kernel"] == kernel
+    assert rep["frac_bins_rel_power_err_gt_1e-5"] <= max_share_beyond_1e5, rep
+    if rep["frac_bins_rel_power_err_gt_1e-5"] > 0:
+        assert rep["those_bins_level_below_frame_peak_db"]["highest"] < -30.0, rep
+    assert rep["max_rel_power_err_bins_within_20dB_of_peak"] <= STRONG_REL, rep
+    assert rep["max_err_relative_to_frame_peak"] <= floor_for(n // 2 + 1), rep
+    assert rep["colour_index_flips_end_to_end"] <= -(-rep["pixels_checked"] // 50000), rep
+    assert rep["fused_image_pixels_differing_from_two_kernel_image"] == 0, rep
+    assert rep["max_abs_db_err"] < 0.1, rep

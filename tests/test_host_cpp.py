@@ -137,22 +137,21 @@ def test_producer_never_waits_for_the_consumer(jsg):
     """a GUI thread hammering getMem / display_update on a C5-sized ring (1875 x 2049, 15 MB per read)
     must not hold up jsg_process_block, and the ring must end up bit-identical to an undisturbed batch run."""
     exe = _build_against_lib(jsg, "producer_latency_test.cpp", "jsg_producer_latency")
-    seen = []
-    for attempt in range(3):   # the functional checks must hold every time; the wall-clock bounds get three attempts (shared host)
-        r = subprocess.run([exe, "400", "300"], capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stdout + r.stderr
-        info = json.loads(r.stdout.strip().splitlines()[-1])
-        print("producer latency under reader load:", info)
-        seen.append(info)
-        assert (info["W"], info["H"]) == (1875, 2049)
-        assert info["reads"] >= 20                      # the consumer really was busy
-        assert info["differing_floats"] == 0 and info["differing_pixels"] == 0 and info["pos_live"] == info["pos_batch"]
-        # one consumer read moves 15 MB over PCIe (hundreds of microseconds); the producer's call stays far below that, and
-        # no call ever waits for a reader's PCIe copy (those take milliseconds)
-        if info["p99_us"] < 150.0 and info["p50_us"] < 60.0 and info["max_after_first_us"] < 1500.0:
-            break
-    else:
-        raise AssertionError(f"producer latency bounds missed in three attempts: {seen}")
+    r = subprocess.run([exe, "400", "300"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    print("producer latency under reader load:", info)
+    assert (info["W"], info["H"]) == (1875, 2049)
+    assert info["reads"] >= 20                      # the consumer really was busy
+    assert info["differing_floats"] == 0 and info["differing_pixels"] == 0 and info["pos_live"] == info["pos_batch"]
+    # One attempt.  One consumer read moves 15 MB over PCIe (hundreds of microseconds) and hundreds of them run while the 400
+    # blocks are pushed: a producer that waited for readers would show it in the median and the 99th percentile at once.
+    # Measured on the pool's boxes: p50 13-17 us, p99 29-45 us (DESIGN.md 1.1; bench.py "boundary").  The bounds sit at 2.5x.
+    assert info["p50_us"] < 40.0, info
+    assert info["p99_us"] < 120.0, info
+    # the single worst call is at the mercy of the (shared) host's scheduler: reported, and only refused where it says that
+    # the call sat behind a reader's PCIe copy more than once over (milliseconds)
+    assert info["max_after_first_us"] < 5000.0, info
 
 
 @pytest.mark.gpu
@@ -165,3 +164,36 @@ def test_several_engines_from_one_host_process(jsg, shards):
     assert r.returncode == 0, r.stdout + r.stderr
     info = json.loads(r.stdout.strip().splitlines()[-1])
     assert info["shards"] == shards and info["shards_differing"] == 0 and info["pos_mismatch"] == 0 and info["columns"] == 24
+
+
+def _build_rccl_example(jsg):
+    libdir = os.path.dirname(jsg.capi.LIB_PATH)
+    exe = os.path.join(tempfile.gettempdir(), "jsg_rccl_absmean_example")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+                           "-isystem", "/opt/rocm/include", os.path.join(ROOT, "tests", "cpp", "rccl_absmean_example.cpp"), "-o", exe,
+                           "-L", libdir, "-ljsg", f"-Wl,-rpath,{libdir}", "-L/opt/rocm/lib", "-lrccl", "-lamdhip64",
+                           "-Wl,-rpath,/opt/rocm/lib", "-lpthread"])
+    return exe
+
+
+def test_rccl_cross_gpu_absmean_example_compiles_and_links(jsg):
+    """the C++ worked example of the one real exchange step of the sharded path -- JSG_MIX_SUM partial sums
+    of linear power -> ncclAllReduce (RCCL over xGMI) -> jsg_db_from_power_launch -- builds against librccl.so and libjsg.so."""
+    if not os.path.exists("/opt/rocm/lib/librccl.so"):
+        pytest.skip("RCCL is not installed")
+    assert os.path.exists(_build_rccl_example(jsg))
+
+
+@pytest.mark.gpu
+def test_rccl_cross_gpu_absmean_example_runs(jsg):
+    """Runs the exchange when the box has at least two GPUs (the driver's 8-GPU node); on a one-GPU box it reports that and
+    exits cleanly -- no collective is invented for a single device."""
+    if not os.path.exists("/opt/rocm/lib/librccl.so"):
+        pytest.skip("RCCL is not installed")
+    exe = _build_rccl_example(jsg)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    if "skipped" not in info:
+        assert info["devices_differing_from_device0"] == 0 and info["max_abs_db_diff_vs_one_device"] < 1e-3

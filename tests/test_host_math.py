@@ -4,6 +4,9 @@ import os
 import re
 
 import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_every_declared_symbol(jsg):
@@ -139,3 +142,32 @@ def test_geometry_fuzz_vs_oracle(jsg, oracle):
         assert jsg.next_power_of_2(ms, fs) == oracle.next_power_of_2(ms, fs)
 
     check()
+
+
+def test_colormap_tables_against_the_reference_build_itself(jsg):
+    """Not through a fixture: the product's tables against oracle/_ref -- /root/reference/CColorpalette.cpp compiled as it
+    lies (oracle/Makefile target `ref`; the built .so travels to the GPU box) -- called live.  This is the check of the two
+    perceptual schemes at 256 colours that does not lean on tests/golden/colormap_ref.json, from which their embedded table
+    (csrc/jsg_colormap_tables.inc) was generated.  Reference: CColorpalette.cpp:106-339 (Viridis :254-271, Plasma :272-289)."""
+    import ctypes
+    so = os.path.join(ROOT, "oracle", "_ref", "libjade_colorpalette_ref.so")
+    if os.path.isdir("/root/reference"):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref is not built (no /root/reference in this environment)")
+    ref = ctypes.CDLL(so)
+    ref.ref_cp_lut.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    for scheme in range(7):
+        for n in (256, 2, 3, 7, 64, 100, 255, 257, 512, 1000):
+            want = np.zeros(n, dtype=np.int32)
+            ref.ref_cp_lut(n, scheme, want.ctypes.data)
+            assert (jsg.colormap_lut(n, scheme) == want).all(), (scheme, n)
+
+
+def test_colormap_tables_match_the_survey_hashes(jsg, oracle, golden):
+    """A second record that is independent of colormap_ref.json: the FNV-1a-32 hashes of the seven 256-colour tables that the
+    survey took from its own run of the reference build (tests/golden/survey_kats.json)."""
+    for scheme, h in golden["kats"]["colormap_fnv1a32_lut256"].items():
+        lut = jsg.colormap_lut(256, int(scheme))
+        assert "%08x" % oracle.fnv1a32(lut.astype("<i4").tobytes()) == h, scheme

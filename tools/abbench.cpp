@@ -404,7 +404,7 @@ int main(int argc, char** argv) {
             }
             // correctness against the first library
             for (int b = 0; b < 1; ++b) {
-                CK(hipMemset(d_out[b], 0, out_bytes));
+                CK(hipMemsetAsync(d_out[b], 0, out_bytes, one));   // on the launch stream (`one` does not synchronise with the null stream)
                 jsg_stft_args a = args_for(b);
                 if (l.stft(plans[li], &a, one) != 0) {
                     std::fprintf(stderr, "%s: launch failed: %s\n", l.path.c_str(), l.last_error ? l.last_error(nullptr) : "?");
@@ -422,7 +422,7 @@ int main(int argc, char** argv) {
             }
             if (c.colour && l.stft_image) {   // fused image of this library against its own two-kernel image
                 std::vector<uint32_t> fimg(got_img.size());
-                CK(hipMemset(d_img[1], 0, img_bytes));
+                CK(hipMemsetAsync(d_img[1], 0, img_bytes, one));
                 jsg_stft_image_args fa{};
                 fa.stft = args_for(1);
                 fa.stft.in = d_in[0];
