@@ -11,15 +11,25 @@ DEVFLAG := $(if $(filter 1,$(DEV)),-DJSG_DEV_VARIANTS,)
 .PHONY: lib oracle test-cpp clean
 lib: $(OUT)
 
-$(OBJ)/jsg_kernels.o: $(SRC)/jsg_kernels.hip $(SRC)/jsg_internal.h include/jsg.h
+HIPFLAGS := -std=c++17 -O3 -fPIC -Iinclude --offload-arch=$(ARCH) -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=16 $(DEVFLAG)
+KDEPS    := $(SRC)/jsg_stft_kernel.h $(SRC)/jsg_internal.h include/jsg.h
+
+$(OBJ)/jsg_kernels.o: $(SRC)/jsg_kernels.hip $(KDEPS)
 	@mkdir -p $(OBJ)
-	$(HIPCC) -std=c++17 -O3 -fPIC -Iinclude --offload-arch=$(ARCH) -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=16 $(DEVFLAG) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+# the 512 / 1024 / 2048 / 8192-point kernels: ILP-first machine scheduler (see the unit's header comment)
+$(OBJ)/jsg_stft_a.o: $(SRC)/jsg_stft_a.hip $(KDEPS)
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -mllvm -amdgpu-sched-strategy=max-ilp -c $< -o $@
+$(OBJ)/jsg_stft_b.o: $(SRC)/jsg_stft_b.hip $(KDEPS)
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(OBJ)/%.o: $(SRC)/%.cpp $(SRC)/jsg_internal.h $(SRC)/jsg_colormap_tables.inc include/jsg.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) -std=c++17 -O3 -fPIC -Iinclude -ffp-contract=off -D__HIP_PLATFORM_AMD__ -c $< -o $@
 
-$(OUT): $(OBJ)/jsg_kernels.o $(OBJ)/jsg_engine.o $(OBJ)/jsg_host_math.o
+$(OUT): $(OBJ)/jsg_kernels.o $(OBJ)/jsg_stft_a.o $(OBJ)/jsg_stft_b.o $(OBJ)/jsg_engine.o $(OBJ)/jsg_host_math.o
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^
 
 oracle:

@@ -11,8 +11,16 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libjsg.so")
 
-SOURCES = ["jsg_kernels.hip", "jsg_engine.cpp", "jsg_host_math.cpp"]
-HEADERS = ["jsg_internal.h", "jsg_colormap_tables.inc", os.path.join(ROOT, "include", "jsg.h")]
+SOURCES = ["jsg_kernels.hip", "jsg_stft_a.hip", "jsg_stft_b.hip", "jsg_engine.cpp", "jsg_host_math.cpp"]
+HEADERS = ["jsg_internal.h", "jsg_stft_kernel.h", "jsg_colormap_tables.inc", os.path.join(ROOT, "include", "jsg.h")]
+# device-compile flags of every .hip unit:
+#   -fno-slp-vectorize: the kernel packs its complex arithmetic into v_pk_*_f32 by hand (re, im in one register pair); the automatic
+#       SLP pass pairs unrelated scalars and pays ~140 register moves per FFT
+#   -amdgpu-kernarg-preload-count: the leading scalar kernel arguments are delivered in SGPRs
+HIP_FLAGS = ["-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
+# ... and per unit: the ILP-first machine scheduler for the 512 / 1024 / 2048 / 8192-point kernels (jsg_stft_a.hip explains and
+# gives the measurements); the 4096-point kernels (jsg_stft_b.hip) keep the default one
+UNIT_FLAGS = {"jsg_stft_a.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 ARCH = "gfx950"
 
 
@@ -50,7 +58,7 @@ def build_variant(name: str, hip_flags, verbose: bool = False) -> str:
             continue
         objs.append(o)
         cmd = [hipcc, "-std=c++17", "-O3", "-fPIC", "-c", s, "-o", o, "-I", os.path.join(ROOT, "include"),
-               f"--offload-arch={ARCH}", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=16"] + list(hip_flags)
+               f"--offload-arch={ARCH}"] + HIP_FLAGS + ([] if os.environ.get("JSG_NO_UNIT_FLAGS") else UNIT_FLAGS.get(src, [])) + list(hip_flags)
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
@@ -81,10 +89,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
             recompiled.append(src)
             cmd = [hipcc, "-std=c++17", "-O3", "-fPIC", "-c", s, "-o", o, "-I", os.path.join(ROOT, "include")]
             if src.endswith(".hip"):
-                # -fno-slp-vectorize: the kernel packs its complex arithmetic into v_pk_*_f32 by hand (re, im in one
-                # register pair); the automatic SLP pass pairs unrelated scalars and pays ~140 register moves per FFT
-                # -amdgpu-kernarg-preload-count: the leading scalar kernel arguments are delivered in SGPRs
-                cmd += [f"--offload-arch={ARCH}", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
+                cmd += [f"--offload-arch={ARCH}"] + HIP_FLAGS + UNIT_FLAGS.get(src, [])
                 if dev:
                     cmd.append("-DJSG_DEV_VARIANTS")
             else:

@@ -1,0 +1,1111 @@
+// The STFT -> dB kernel of libjsg.so and everything that instantiates it (lane tables, launch helpers).  Included by the
+// translation units that hold the kernels: jsg_stft_a.hip (512 / 1024 / 2048 / 8192 points) and jsg_stft_b.hip (4096 points) --
+// two units because the two groups want different instruction schedulers (see jadespectrogram_amd/_build.py) -- and by
+// jsg_kernels.hip, which owns the plan, the launcher and the C-ABI and calls the per-plan entry points declared at the end.
+//
+//   stft_db_kernel   L lanes transform one real frame (64 = one wavefront per frame; 32: two frames per wave at
+//                    N = 512 and in the two-stage N = 2048 plan; 128 / 256: two / four wavefronts per frame at
+//                    N = 4096 / 8192):
+//                    lane tables (window, twiddles) staged once per workgroup into LDS, issued ahead of the frame
+//                    loads so that the one workgroup barrier completes while those are in flight; coalesced 8-byte
+//                    loads of the frame straight from the audio stream in HBM, software-prefetched (the 50..87.5 %
+//                    overlap of neighbouring frames is served by L1/L2: neighbouring frames sit in one workgroup);
+//                    window multiply; N/2-point complex FFT as three register-resident radix stages with two
+//                    bank-conflict-free LDS exchanges (wave-private and barrier-free for L <= 64), or two radix-32
+//                    stages with one exchange (Cfg2048B); paired real-split post pass (X[k] and X[N/2-k] from one
+//                    butterfly, both |X|^2 formed side by side in packed math); channel mix in registers (pair
+//                    accumulators); 10*log10 on the hardware log unit; non-temporal 256-byte coalesced ring stores.
+//                    No MFMA: the path is bandwidth / latency / VALU-issue bound, not a contraction.
+//                    Replaces Spectrogram.cpp:50-119 + :137-145 + spectrum::power (call site :144) of the reference.
+//   colormap_kernel  dB ring columns -> ARGB image rows (transpose through LDS so both sides are coalesced),
+//                    CColorPalette::getRGBColor inlined.  Replaces Spectrogram.cpp:632-648 / :673-680 / :693-700.
+//
+// The index algebra, the twiddle tables and the LDS layouts are modelled and checked in tools/fft_model.py.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "../../include/jsg.h"
+#include "jsg_internal.h"
+
+namespace jsg {
+
+// ------------------------------------------------------------------------------------------------------------
+// complex arithmetic on packed pairs: cf = (re, im) in one aligned 64-bit VGPR pair.
+//
+// A wave64 VALU instruction occupies its SIMD for ~4 cycles unless four or more waves of that SIMD have VALU work
+// ready at the same time (measured: tools/probes/valu_rate.hip; this kernel sits at ~4.1 cycles per instruction, PMC
+// SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU), and a packed v_pk_{add,mul,fma}_f32 performs two float operations in such a
+// slot.  A complex add is one packed add, a complex multiply is a packed multiply plus a packed fma, and a
+// multiplication by -i costs nothing: it is folded into the operand-select / negate modifiers of the consuming
+// instruction.  The compiler only derives the broadcast and whole-vector-negate forms of those modifiers from vector
+// code, so the swizzled forms are written out as inline assembly.
+// ------------------------------------------------------------------------------------------------------------
+typedef float cf __attribute__((ext_vector_type(2)));
+
+// a + (-i) b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ cf add_mi(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a - (-i) b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ cf sub_mi(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + conj(b) = (a.x + b.x, a.y - b.y)   and   a - conj(b) = (a.x - b.x, a.y + b.y)
+__device__ __forceinline__ cf add_conj(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cf sub_conj(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a * w (complex): t = (a.x w.x, a.y w.x);  r = (t.x - a.y w.y, t.y + a.x w.y)
+__device__ __forceinline__ cf cmul(cf a, cf w) {
+    cf r;   // one asm statement: between two of them the hazard recognizer pads an s_nop
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+        : "=&v"(r) : "v"(a), "v"(w));
+    return r;
+}
+
+// (a.x + b.x, a.x - b.x) and (a.y + b.y, a.y - b.y): the real parts, and the imaginary parts, of a + b and a - b side by side
+__device__ __forceinline__ cf addsub_re(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cf addsub_im(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// cos/sin(2*pi*i/32), i = 0..7 (compile-time twiddles of the in-register radix butterflies, first quadrant)
+__device__ constexpr float kCos32[8] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                                        0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f,
+                                        0.19509032201612826785f};
+__device__ constexpr float kSin32[8] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
+                                        0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f,
+                                        0.98078528040323044913f};
+
+// cos/sin(2*pi*i/64), i = 0..15: the uniform factors W_64^rho of the factorised post-pass twiddles (Cfg::TWF)
+__device__ constexpr float kCos64[16] = {1.00000000000000000000f, 0.99518472667219692873f, 0.98078528040323043058f, 0.95694033573220882438f, 0.92387953251128673848f, 0.88192126434835504956f, 0.83146961230254523567f, 0.77301045336273699338f, 0.70710678118654757274f, 0.63439328416364548779f, 0.55557023301960228867f, 0.47139673682599780857f, 0.38268343236508983729f, 0.29028467725446233105f, 0.19509032201612833135f, 0.09801714032956077016f};
+__device__ constexpr float kSin64[16] = {0.00000000000000000000f, 0.09801714032956060363f, 0.19509032201612824808f, 0.29028467725446233105f, 0.38268343236508978178f, 0.47139673682599764204f, 0.55557023301960217765f, 0.63439328416364548779f, 0.70710678118654746172f, 0.77301045336273699338f, 0.83146961230254523567f, 0.88192126434835493853f, 0.92387953251128673848f, 0.95694033573220893540f, 0.98078528040323043058f, 0.99518472667219681771f};
+
+// a * w with a wave-uniform w (scalar registers; same arithmetic as cmul)
+__device__ __forceinline__ cf cmul_s(cf a, cf w) {
+    cf r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+        : "=&v"(r) : "v"(a), "s"(w));
+    return r;
+}
+
+// v * exp(-2*pi*i*Q/R) for a first-quadrant exponent (Q < R/4); exponents R/4 <= J < R/2 are this times a pending -i
+template <int Q, int R>
+__device__ __forceinline__ cf mul_w_q1(cf v) {
+    constexpr int idx = Q * (32 / R);
+    static_assert(idx >= 0 && idx < 8, "first quadrant");
+    if constexpr (idx == 0) {
+        return v;
+    } else if constexpr (idx == 4) {   // (1 - i)/sqrt(2) * v = (v + (-i) v)/sqrt(2)
+        return add_mi(v, v) * 0.70710678118654752440f;
+    } else {                           // (c - i s)(x + i y) = (c x + s y) + i (c y - s x)
+        constexpr float c = kCos32[idx], sn = kSin32[idx];
+        const cf t = v * c;
+        const cf sv = {sn, sn};
+        cf r;
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(v), "v"(sv), "v"(t));
+        return r;
+    }
+}
+
+// In-register decimation-in-frequency DFT of R points, natural order in and out (the bit reversal is a compile-time
+// renaming of registers).  UR: the upper half of the inputs carries a pending factor -i (the twiddles W_R^J with
+// J >= R/4 of the layer before); it is absorbed by this layer's butterflies.  R = 8: 28 packed VALU ops, R = 16: 84.
+template <int R, bool UR>
+__device__ __forceinline__ void dft(cf (&x)[R]);
+
+template <int R, bool UR, int J>
+struct DifLayer {
+    static __device__ __forceinline__ void run(const cf (&x)[R], cf (&a)[R / 2], cf (&b)[R / 2]) {
+        const cf lo = x[J], hi = x[J + R / 2];
+        a[J] = UR ? add_mi(lo, hi) : lo + hi;
+        const cf d = UR ? sub_mi(lo, hi) : lo - hi;
+        constexpr int Q = J % (R / 4);   // W_R^J = (-i) W_R^(J - R/4) for J >= R/4: the -i stays pending (dft<R/2, true>)
+        b[J] = mul_w_q1<Q, R>(d);
+        if constexpr (J + 1 < R / 2) DifLayer<R, UR, J + 1>::run(x, a, b);
+    }
+};
+
+template <int R, bool UR = false>
+__device__ __forceinline__ void dft(cf (&x)[R]) {
+    if constexpr (R == 2) {
+        const cf a = x[0], b = x[1];
+        x[0] = UR ? add_mi(a, b) : a + b;
+        x[1] = UR ? sub_mi(a, b) : a - b;
+    } else if constexpr (R > 2) {
+        cf a[R / 2], b[R / 2];
+        DifLayer<R, UR, 0>::run(x, a, b);
+        dft<R / 2, false>(a);
+        dft<R / 2, true>(b);   // b[J], J >= R/4, still lacks its factor -i
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q) {
+            x[2 * q] = a[q];
+            x[2 * q + 1] = b[q];
+        }
+    }
+}
+
+// Lanes of one wavefront run in lock-step, so a wave-private LDS exchange needs no s_barrier; what it does need is
+// that the COMPILER keeps the stores ahead of the loads that other lanes of the same wave perform.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// two floats that are only 4-byte aligned (odd hop sizes such as the reference's perc10 hop of 205 samples)
+struct __attribute__((packed, aligned(4))) f2u {
+    float x, y;
+};
+__device__ __forceinline__ cf to_cf(const f2u& v) { return cf{v.x, v.y}; }
+
+// ------------------------------------------------------------------------------------------------------------
+// per-size configuration (mirrors tools/fft_model.py CONFIGS; layouts found by its conflict search)
+// ------------------------------------------------------------------------------------------------------------
+// TLOC: where the lane tables (window pairs, stage-1/2 twiddles, post-pass twiddles; layout: Cfg::TAB_*) live:
+//   0 = read from global memory (L1/L2) at every use, 1 = brought into LDS once per workgroup and read from there.
+// FPW:  frames a wavefront transforms at the same time, as one interleaved instruction stream (L = 64 plans; every stage of
+//   the kernel loops over the frames inside one basic block).  The idea: two independent dependency chains fill each
+//   other's LDS round trips, tables and address arithmetic are paid once per pair.  Measured with FPW = 2 (4-wave
+//   workgroups, 100 VGPRs): bit-identical results, but C2 5.89 instead of 5.20 us per launch and -4 % on 65 536-frame
+//   launches -- four independent wavefronts per SIMD hide latency better than two twice-as-long ones, and a wave has to
+//   wait for both frames' data.  All plans use 1 (tried and measured).
+// ABL:  development ablations (builds with -DJSG_X_ABL=n): 1 = memory traffic only, 2 = compute only, 3 = in-kernel
+//   stamps, 5 = return at once (launch cost of the kernel's resource footprint).
+template <int N_, int R1_, int R2_, int R3_, int L_, int S1_, int AX_, int AY_, int AZ_, int WPB_, int TLOC_, int WPS_,
+          int FPW_ = 1, int ABL_ = 0, int TWF_ = 0>
+struct Cfg {
+    static constexpr int ABL = ABL_;
+    // TWF: factorised twiddle tables (for plans whose full lane tables do not fit beside the exchange buffers).  The stage-2
+    // twiddle W_M^(n3 (k1 + R1 k2)) is read as B[n3][k2] = W_(M/R1)^(n3 k2) (one row per n3, shared by the lanes) times the
+    // lane's constant A[v] = W_M^(n3 k1); the post-pass twiddle -i W_N^(ll + L rho) as the lane's constant C = -i W_N^ll times
+    // the wave-uniform W_(N/L)^rho (compile-time constants, N / L = 64).  One more complex multiply per value, 24 KB less LDS.
+    static constexpr bool TWF = TWF_ != 0;
+    static constexpr int N = N_, M = N_ / 2, R1 = R1_, R2 = R2_, R3 = R3_, L = L_;
+    static constexpr int P = M / L;                  // complex values per lane
+    static constexpr int U1 = P / R1, U2 = P / R2, U3 = P / R3;
+    static constexpr int S1 = S1_, AX = AX_, AY = AY_, AZ = AZ_;
+    static constexpr int SUB = L < 64 ? 64 / L : 1;  // frames side by side in one wavefront (L = 32: two)
+    static constexpr int WPF = L > 64 ? L / 64 : 1;  // wavefronts per frame (L = 128, 256: the exchanges use s_barrier)
+    static constexpr int FPW = FPW_;                 // frames interleaved in one wavefront's instruction stream
+    static constexpr int TL = L;                     // entries per lane-table row (L = 32: both half-waves read the same entries)
+    static constexpr bool TWO_STAGE = R3_ == 1;      // R1 * R2 = M: one exchange, the second radix stage leaves bin ll + L*k2 in register k2
+    static constexpr int WPB = WPB_;                 // wavefronts per workgroup
+    static constexpr int TPB = WPB * 64 / L * FPW;   // frames per workgroup per iteration
+    static constexpr int TLOC = TLOC_;
+    static constexpr int WPS = WPS_;                 // waves per SIMD the register allocator is asked to allow
+    // Lane tables (float2 elements): window pairs [P][TL]; stage-1 twiddles W_{R1 R2}^{n2 k1}, which depend on the lane
+    // only through n2 = t1 / R3, stored once per n2 as [R2][TS1]; stage-2 twiddles [P][TL]; post-pass twiddles of the
+    // lower half of the bins [P/2][TL].
+    // They are read two values (16 bytes) at a time: ds_read_b128 moves 1 KiB per wave-instruction at the full LDS rate
+    // even with one or two waves per SIMD, 8-byte reads need about four (MI355X_MICROARCH.md, LDS), and every table
+    // value is used by exactly one instruction -- so value j of a lane sits next to value j+1: element (j, e) of a
+    // [J][TL] table is stored at ((j / 2) * TL + e) * 2 + j % 2.  Stage-1 rows hold k1 = 1.. at column k1 - 1, row stride
+    // R1 + 2 (16-byte aligned rows whose 16-byte chunks fall into different banks for the n2 groups of a wave).
+    static constexpr int TS1 = R1_ + 2;
+    static constexpr int tab_idx(int j, int e) { return ((j / 2) * L_ + e) * 2 + j % 2; }
+    static constexpr int TSB = R2_ + 2;              // TWF: row stride of B (16-byte aligned rows in different banks)
+    static constexpr int TAB_WIN = 0, TAB_TW1 = P * TL, TAB_TW2 = TAB_TW1 + R2_ * TS1;
+    static constexpr int TAB_A = TAB_TW2 + R3_ * TSB;                                   // TWF: [U2][TL] behind B
+    static constexpr int TAB_POST = TWF ? TAB_A + U2 * TL : TAB_TW2 + (TWO_STAGE ? 0 : P * TL);   // TWF: C[TL]
+    static constexpr int TAB_ELEMS = TAB_POST + (TWF ? TL : (P / 2) * TL);
+    static constexpr int e1max = (R1 - 1) * S1 + M / R1;
+    static constexpr int e2max = TWO_STAGE ? 0 : (R1 - 1) * AX + (R2 - 1) * AY + (R3 - 1) * AZ + 1;
+    static constexpr int raw = e1max > e2max ? (e1max > M + 1 ? e1max : M + 1) : (e2max > M + 1 ? e2max : M + 1);
+    static constexpr int LDS_ELEMS = (raw + 1) & ~1;  // float2 elements per frame slot, 16-byte multiple
+    static constexpr int LDS_BYTES = LDS_ELEMS * TPB * 8;                          // dynamic: exchange buffers
+    static constexpr int LDS_TOTAL = LDS_BYTES + (TLOC == 1 ? TAB_ELEMS : 2) * 8;  // + static: lane tables
+    static_assert(R1 * R2 * R3 == M, "radices");
+    static_assert(P % R1 == 0 && P % R2 == 0 && P % R3 == 0, "each lane owns whole butterflies");
+    static_assert(WPB % WPF == 0, "a workgroup holds whole frames");
+    static_assert(FPW == 1 || L == 64, "interleaved frames: one-wavefront-per-frame plans only");
+    static_assert(TLOC == 0 || TLOC == 1, "lane tables in registers: removed (DESIGN.md, tried and measured)");
+    static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget of one CU");
+    static_assert(!TWF || ((N_ / L_ == 64 || N_ / L_ == 32) && L_ % R3_ == 0 && !TWO_STAGE && TLOC_ == 1), "factorised tables: 4096-point plans");
+};
+
+#ifndef JSG_X_ABL
+#define JSG_X_ABL 0
+#endif
+#ifndef JSG_X_FPW1024      // frames per wavefront / wavefronts per workgroup of the 1024-point plan (A/B builds)
+#define JSG_X_FPW1024 1
+#endif
+#ifndef JSG_X_WPB1024
+#define JSG_X_WPB1024 (8 / JSG_X_FPW1024)
+#endif
+#ifndef JSG_X_FPW2048
+#define JSG_X_FPW2048 1
+#endif
+#ifndef JSG_X_WPB2048
+#define JSG_X_WPB2048 4
+#endif
+#ifndef JSG_X_WPS2048
+#define JSG_X_WPS2048 3
+#endif
+using Cfg512 = Cfg<512, 8, 8, 4, 32, 36, 4, 33, 1, 8, 1, 2>;   // (a 80-VGPR budget = 3 workgroups per CU measured no faster)
+using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, JSG_X_WPB1024, 1, 2, JSG_X_FPW1024, JSG_X_ABL>;
+#ifndef JSG_X_TWF2048      // factorised stage-2 / post tables (Cfg::TWF): 11.3 instead of 21.2 KB of tables, so that THREE 4-wave
+#define JSG_X_TWF2048 1    // workgroups fit a CU (12 waves instead of 8): stereo launches -9..-13 %, mono -1..-5 %
+#endif
+using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, JSG_X_WPB2048, 1, JSG_X_WPS2048, JSG_X_FPW2048, 0, JSG_X_TWF2048>;   // (6-, 8-, 12-wave workgroups: no faster)
+// 2048 points as TWO radix-32 stages with ONE exchange: 32 lanes per frame, 32 complex values per lane, two frames side by side
+// in a wavefront.  Against the three-stage plan (16*8*8, 64 lanes): the same butterfly count, but 40 % fewer LDS
+// instructions per frame (one exchange of 16 + 16 instead of two of 32 + 32), which is what capped C3 (VALU and LDS
+// each about half busy at two waves per SIMD).  One 8-wave workgroup per CU: 16 frames * 8.7 KB of exchange + 21 KB of tables.
+// It needs 210-252 VGPRs (two waves per SIMD) and 156 KB of LDS, so a CU holds exactly one such workgroup, which is launched
+// once per CU and loops over its frames.  For launches that fill the GPU in whole rounds of 256 workgroups it is ahead of the
+// three-stage plan, the more channels are mixed into a column the more (8 ch -10..-13 %, 4 ch -3..-8 %, 1-2 ch level);
+// for anything smaller the 4-frame workgroups of the three-stage plan use more CUs (tools/abbench --cfg x2048 / mid).
+// The launcher picks by channel count and by how well the launch fills its rounds (stft_launch_impl).
+using Cfg2048B = Cfg<2048, 32, 32, 1, 32, 34, 0, 0, 0, 8, 1, 1>;
+constexpr int k2048B_min_channels = 3;   // channels mixed into one column from which the two-stage plan is the faster one
+constexpr int k4096B_min_channels = 1;   // ... the one-wavefront-per-frame 4096-point plan is ahead at every channel count once the rounds are
+                                         // full (round 3, 16 384 FFTs, inputs and rings rotating over 1 GB: mono 66.5 vs 73.4 us, stereo 56.7 vs 60.8,
+                                         // 4 ch 51.6 vs 57.6, 8 ch 50.3 vs 54.7); launches that do not fill their rounds keep the two-wave plan
+// The "B" plans run ONE 8-wave workgroup per CU (16 / 8 frames at a time), i.e. a launch proceeds in rounds of <CU count> workgroups:
+// a launch that fills its last round badly leaves CUs idle where the small workgroups of the other plan would fill them
+// (1024 stereo 2048-point frames: 7.2 vs 13.0 us).  At full rounds "B" is about 13 % faster, so it is used when the rounds of
+// the launch are at least 87 % full (224..256 workgroups on 256 CUs, 446..512, ..., everything from 7 rounds on).  Sub-launches of one
+// stream that fall on different sides of that rule therefore agree within the float32 bound, not bit for bit; everything
+// with one or two channels per column, and the engine's per-block launches, always take the small-workgroup plan.
+constexpr double kB_min_round_fill = 0.87;
+#ifndef JSG_X_WPB4096
+#define JSG_X_WPB4096 4
+#endif
+#ifndef JSG_X_WPS4096
+#define JSG_X_WPS4096 1
+#endif
+#ifndef JSG_X_TLOC4096
+#define JSG_X_TLOC4096 1
+#endif
+#ifndef JSG_X_TWF4096
+#define JSG_X_TWF4096 0
+#endif
+using Cfg4096 = Cfg<4096, 16, 8, 16, 128, 144, 1, 272, 17, JSG_X_WPB4096, JSG_X_TLOC4096, JSG_X_WPS4096, 1, 0, JSG_X_TWF4096>;
+// 4096 points with ONE wavefront per frame: 8*16*16, 32 complex values per lane, both exchanges wave-private (no workgroup
+// barrier at all), one 8-wave workgroup per CU.  8 x 17.6 KB of exchange leave 22 KB of LDS for tables, so only the window
+// and the stage-1 rows are kept whole and the other two tables are factorised (Cfg::TWF: one more complex multiply per
+// value).  Like Cfg2048B it trades waves per SIMD for independence of the waves: measured (abbench --cfg x4096, 16 384 FFTs,
+// us three-stage two-wave plan -> this one) 8 ch 56.4 -> 48.4, 4 ch 57.2 -> 52.5, 2 ch 59.4 -> 60.6 (61.4 -> 67.4 at 50 %
+// overlap), 1 ch 66.4 -> 79.1: it is the plan of the launches that mix >= 3 channels into a column.
+using Cfg4096B = Cfg<4096, 8, 16, 16, 64, 272, 276, 17, 1, 8, 1, 1, 1, 0, 1>;    // two wavefronts per frame, two frames per workgroup
+// four wavefronts per frame, one frame per workgroup.  Its full lane tables (82 KB) do not fit beside the exchange buffer,
+// and reading them from L2 at every use cost 12 %: the factorised set (Cfg::TWF, 40.7 KB) lives in LDS like everywhere else.
+using Cfg8192 = Cfg<8192, 16, 16, 16, 256, 272, 1, 272, 17, 4, 1, 1, 1, 0, 1>;
+// (frames of more than one wavefront exchange through the workgroup barrier, so every further frame in the workgroup joins
+// five barriers per FFT: 8-wave workgroups were 9-15 % slower, 12-wave ones 30 %)
+
+struct StftKArgs {
+    const float* in;
+    long long in_pitch;
+    int hop, feedblocks;
+    int regular;         // hop * feedblocks == N: frame j starts at j*hop (no division in the kernel)
+    int c_begin, c_end;  // channel range that is combined into one column (mixed modes)
+    int per_channel;     // one column per (channel, frame): blockIdx.y is the channel
+    int linear;          // store linear power instead of dB
+    float scale;         // AbsMean: 1/C (exact for power-of-two C); others: 1
+    float divisor;       // AbsMean: float(C)
+    int exact_div;       // C is not a power of two: divide (IEEE) instead of scaling
+    unsigned first_frame, n_frames;
+    float* out;
+    long long out_pitch, out_cpitch;
+    int ring_w, ring_pos;
+    int iters;
+    const float2* tab;   // lane tables (Cfg::TAB_* layout): window pairs, stage-1 / stage-2 twiddles, post-pass twiddles
+    unsigned long long* stamps;   // development (ABL == 3): s_memtime stamps per wave
+    int xcd_remap;                // 1: XCD-aware block remap (default); 0: identity (development A/B)
+    int chunked;                  // 0: grid-stride traversal (default); 1: one contiguous chunk per workgroup
+    // OUTK == 1 (fused display path): the column leaves as 8-bit palette indices instead of dB floats
+    unsigned char* idx;
+    long long idx_pitch;          // bytes between index columns
+    float vmin, vmax, top, mult;  // CColorPalette::setValueRange / getRGBColor (CColorpalette.cpp:39-54, CColorpalette.h:34-45)
+    int n_colors;
+    // OUTK == 2 (single-kernel display path): the workgroup turns the columns of an iteration into ARGB image rows itself
+    unsigned* argb;               // image [height][argb_pitch], pixel (x, height - 1 - bin)
+    long long argb_pitch;
+    const int* lut;               // n_colors entries 0x00RRGGBB
+    int x_first, x_wrap;          // column i of the launch lands at x = (x_first + i) % x_wrap
+};
+
+// dB = 10*log10(p + 1e-11f) -- reference Spectrogram.cpp:107 with g_minValForLogSpectrogram (:36).
+// v_log_f32 (log2, 1 ulp) times float(10*log10(2)); inputs are >= 1e-11, never denormal.  The constant's rounding
+// (<= 6e-8 relative) stays below half an ulp of the dB value, so no hi/lo split is spent on it.
+__device__ __forceinline__ float to_db(float p) {
+    return __builtin_amdgcn_logf(p + 1e-11f) * 3.0102999566398120f;
+}
+
+// CColorPalette::getRGBColor's index (reference CColorpalette.h:34-45), float32 arithmetic, truncation.
+__device__ __forceinline__ int color_index(float v, float vmin, float vmax, float top, float mult, int n_colors) {
+    if (v >= vmax) v = top;          // value = m_Max*0.9999f
+    if (v < vmin) v = vmin;
+    int idx = (int)((v - vmin) * mult);
+    return idx < n_colors ? idx : n_colors - 1;
+}
+
+template <int MIXOP>
+__device__ __forceinline__ float mix_combine(float acc, float pw) {
+    if constexpr (MIXOP == 0) return acc + pw;                  // AbsMean / Sum: m_powerfinal += m_power[cc]  (:72)
+    else if constexpr (MIXOP == 1) return pw > acc ? pw : acc;  // Max (:81)
+    else if constexpr (MIXOP == 2) return pw < acc ? pw : acc;  // Min (:89)
+    else return pw;                                             // one channel per column: 0 + pw == pw exactly
+}
+
+// the same on a pair (bin k, bin M - k)
+template <int MIXOP>
+__device__ __forceinline__ cf mix_combine2(cf acc, cf pw) {
+    if constexpr (MIXOP == 0) return acc + pw;
+    else if constexpr (MIXOP == 1) return cf{pw.x > acc.x ? pw.x : acc.x, pw.y > acc.y ? pw.y : acc.y};
+    else if constexpr (MIXOP == 2) return cf{pw.x < acc.x ? pw.x : acc.x, pw.y < acc.y ? pw.y : acc.y};
+    else return pw;
+}
+
+#define GETREG_HW_ID ((32 - 1) << 11 | 4)   // s_getreg_b32 hwreg(HW_REG_HW_ID, 0, 32)
+
+// MIXOP: 0 sum over a channel range (AbsMean, Sum), 1 max, 2 min, 3 exactly one channel per column (mono, Left, Right,
+// per-channel): the channel bookkeeping folds away and every iteration ends in the store epilogue, which makes the
+// number of vector-memory instructions per iteration a compile-time fact -- the s_waitcnt the compiler places in
+// front of the next frame's data then counts past the (younger) column stores instead of waiting for their
+// write acknowledgements.
+//
+// JSG_NO_LDS_MERGE: the backend's load/store optimizer fuses pairs of 8-byte LDS accesses into ds_read2_b64 /
+// ds_read2st64_b64.  On gfx950 a ds_read_b64 is serviced as 2 x 32 lanes (2 LDS cycles, 256 B/clk) but a ds_read2_b64 as
+// two accesses of 4 x 16 lanes (8 cycles, 128 B/clk) -- MI355X_MICROARCH.md, LDS table -- so the fused form halves the
+// read bandwidth of the exchange reads, on the busiest shared pipe of this kernel.  The pass is switched off for this
+// kernel only.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(JSG_X_LDS_MERGE)
+#define JSG_NO_LDS_MERGE __attribute__((target("no-load-store-opt")))
+#else
+#define JSG_NO_LDS_MERGE
+#endif
+// OUTK: 0 = the column is stored as floats (dB, or linear power), 1 = as 8-bit palette indices (fused display path:
+// the dB value never goes to memory; reference Spectrogram.cpp:632-648 consumes the column it has just produced),
+// 2 = the workgroup colours its columns itself (one-wavefront-per-frame plans): the palette indices of the TPB consecutive
+// columns of an iteration are parked in the (then idle) exchange regions, and after a workgroup barrier all waves write
+// ARGB image rows -- runs of TPB pixels (32 bytes for the eight-frame workgroups) per row.  Neither the dB column nor an index
+// column goes to memory: per C5 column 4096 B in + 8196 B out, the algorithmic bytes.
+template <class C, int MIXOP, int OUTK = 0>
+__global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_kernel(
+    // Everything the table and frame loads depend on sits in the first 16 dwords of the kernel arguments: with
+    // -amdgpu-kernarg-preload-count=16 those arrive in SGPRs with the wave, so the loads are issued without waiting for a
+    // scalar-memory round trip to the kernarg segment (4096 waves starting at once queue up on the scalar cache:
+    // measured 0.47 us median / 1.1 us p90 from wave start to the first frame load before this ordering, tools/abbench
+    // --stamps).  The rest (output geometry, mix scale) is fetched by s_load while the frame is in flight.
+    const float* __restrict__ k_in, const long long k_in_pitch, const float2* __restrict__ k_tab, const unsigned k_n_frames,
+    const unsigned k_first_frame, const int k_hop, const int k_flags, const unsigned k_c_range, const int k_iters,
+    const unsigned k_nblk, const int k_feedblocks, const StftKArgs a_rest) {   // 14 dwords are preloaded; k_c_range = c_begin | c_end << 16
+    if constexpr (C::ABL == 5) { if (k_iters != -12345) return; }   // ablation: launch cost of this kernel's resource footprint
+    StftKArgs a = a_rest;
+    a.in = k_in; a.in_pitch = k_in_pitch; a.n_frames = k_n_frames; a.first_frame = k_first_frame; a.hop = k_hop;
+    a.iters = k_iters; a.regular = k_flags & 1; a.per_channel = (k_flags >> 1) & 1; a.c_begin = int(k_c_range & 0xffffu); a.c_end = int(k_c_range >> 16);
+    a.xcd_remap = (k_flags >> 2) & 1; a.chunked = (k_flags >> 3) & 1; a.tab = k_tab; a.feedblocks = k_feedblocks;
+    // Two distinct LDS objects on purpose: the (read-only) lane tables and the exchange buffers.  With one object
+    // the compiler must assume that a table read may alias an exchange store and serialises them.
+    __shared__ __attribute__((aligned(16))) cf s_tab[C::TLOC == 1 ? C::TAB_ELEMS : 2];
+    __shared__ int s_lut[OUTK == 2 ? 256 : 1];
+    static_assert(OUTK != 2 || (C::L == 64 && C::FPW == 1 && C::LDS_TOTAL + 1024 <= 160 * 1024), "single-kernel display path: one wavefront per frame");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int L = C::L, P = C::P, M = C::M, R1 = C::R1, R2 = C::R2, R3 = C::R3, F = C::FPW;
+    constexpr int U1 = C::U1, U2 = C::U2, U3 = C::U3;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps task math scalar
+    // frame slot inside the workgroup and lane index inside the frame (L lanes cooperate on one frame); a wavefront of an
+    // L <= 64 plan owns the SUB * F consecutive slots from slot0 on: slot0 + sub * F + f
+    const int ll = L <= 64 ? lane % L : (wave % C::WPF) * 64 + lane;
+    const int sub = L <= 64 ? lane / L : 0;
+    const int slot0 = L <= 64 ? wave * C::SUB * F : wave / C::WPF;   // wave-uniform part of the slot
+    cf* const lds0 = reinterpret_cast<cf*>(smem_raw) + (slot0 + sub * F) * C::LDS_ELEMS;   // frame f: lds0 + f * LDS_ELEMS
+    const int tl = ll;                                            // index into a lane-table row (TL = L entries)
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, stA = 0, stC = 0, stP = 0, rt0 = 0;
+    if constexpr (C::ABL == 3) { st0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+
+    // XCD-aware block remap (bijective): blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD one
+    // contiguous range of frames so that the overlapped halves of neighbouring frames hit the same L2.
+    const unsigned nblk = k_nblk, b = blockIdx.x;   // == gridDim.x (a hidden kernel argument: would cost an s_load)
+    const unsigned q = nblk >> 3, r = nblk & 7, xcd = b & 7;
+    const unsigned lb = a.xcd_remap ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3) : b;
+
+    // ---- task bookkeeping (32-bit, scalar): task t of this launch is frame t; the channel range is fixed ----
+    // Grid-stride traversal: in iteration `it` the workgroups cover one contiguous window of gridDim.x*TPB frames that
+    // sweeps through the stream (neighbouring workgroups touch neighbouring DRAM pages at the same time), instead
+    // of every workgroup streaming through a private region (thousands of concurrent streams: 10-15 % less HBM
+    // bandwidth, see tools/copy_width_probe.py).  JSG_TRAVERSAL=chunk selects the old order (development A/B).
+    const unsigned task_stride = a.chunked ? C::TPB : nblk * C::TPB;
+    const unsigned task0 = (a.chunked ? lb * (unsigned)a.iters * C::TPB : lb * C::TPB) + slot0;   // first task of this wave
+    const int c0 = a.per_channel ? (int)blockIdx.y : a.c_begin;
+    const int c1 = a.per_channel ? (int)blockIdx.y + 1 : a.c_end;
+    constexpr bool ONE = MIXOP == 3;
+    const int nc = ONE ? 1 : c1 - c0;
+    __builtin_assume(a.iters >= 1 && nc >= 1);   // (the launcher guarantees it) keeps the first frame's loads unconditional
+    const int n_fft = a.iters * nc;   // FFT rounds this wave performs (F frames each), s = it*nc + (c - c0)
+    // task (= frame of the launch) of frame f of this lane in iteration `it`; tasks past the end are given the last frame
+    // again: they hold the same bits as that frame's own lanes and store them to the same column, so nothing is masked
+    auto task_of = [&](unsigned it, int f) -> unsigned {
+        unsigned t = task0 + it * task_stride + sub * F + f;
+        return t < a.n_frames ? t : a.n_frames - 1;
+    };
+    auto frame_src = [&](int s, int f) -> const f2u* {
+        const unsigned it = (nc == 1) ? (unsigned)s : (unsigned)s / (unsigned)nc;
+        const int c = c0 + (s - (int)it * nc);
+        const unsigned j = a.first_frame + task_of(it, f);
+        long long start;
+        if (a.regular) {
+            start = (long long)j * a.hop;
+        } else {   // the reference's perc10: every fft-size block restarts at offset 0 (Spectrogram.cpp:50-55,216)
+            const unsigned blk = j / (unsigned)a.feedblocks;
+            start = (long long)blk * C::N + (long long)(j - blk * a.feedblocks) * a.hop;
+        }
+        return reinterpret_cast<const f2u*>(a.in + (long long)c * a.in_pitch + start) + ll;
+    };
+
+    // ---- lane tables first: two 16-byte LDS-DMA pieces per thread bring the tables from L2 straight into LDS (wave-uniform
+    //      base + lane * 16 bytes, no VGPR round trip).  They are issued AHEAD of the frame loads: every wave's FFT start is
+    //      gated by the workgroup barrier behind the tables, so they are the latency-critical load (frame loads first, or
+    //      half of them first, measured 0.3-0.5 us slower per C2 launch) ----
+    constexpr int NTL = C::TLOC == 1 ? (C::TAB_ELEMS / 2 + C::WPB * 64 - 1) / (C::WPB * 64) : 1;   // 16-byte pieces per thread
+    constexpr bool TAB_EVEN = (C::TAB_ELEMS / 2) % (C::WPB * 64) == 0;
+    if constexpr (C::ABL == 3) { asm volatile("" ::"s"(task0), "s"(task_stride)); stP = __builtin_readcyclecounter(); }
+    if constexpr (C::TLOC == 1) {
+        const v4f* g4 = reinterpret_cast<const v4f*>(a.tab) + threadIdx.x;
+        char* sbase = reinterpret_cast<char*>(s_tab) + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NTL; ++i)
+            if (TAB_EVEN || i + 1 < NTL || (int)threadIdx.x + i * C::WPB * 64 < C::TAB_ELEMS / 2)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g4 + i * C::WPB * 64),
+                                                 (__attribute__((address_space(3))) void*)(sbase + i * C::WPB * 1024), 16, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // pin the order of the table pieces against the frame loads (in-order vmcnt)
+    }
+    // ---- issue the loads of the first FFT round (software pipeline, one round ahead) ----
+    f2u raw[F][P];
+    if constexpr (C::ABL == 3) stA = __builtin_readcyclecounter();
+    if constexpr (C::ABL != 2) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const f2u* src = frame_src(0, f);
+#pragma unroll
+            for (int m = 0; m < P; ++m) raw[f][m] = src[L * m];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const cf* tBase;   // start of the tables (LDS copy, or global memory for TLOC == 0)
+    if constexpr (C::TLOC == 1) {
+        // the table pieces are older than the F * P frame loads of this wave: a counted vmcnt retires them and leaves the
+        // frames in flight (an LDS-DMA is a pending LDS write on the VM counter; __syncthreads() would drain everything)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (compiler only) the frame loads stay above the counted wait
+        if constexpr (C::ABL != 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(F * P) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if constexpr (C::ABL == 3) stC = __builtin_readcyclecounter();
+        tBase = s_tab;
+    } else {
+        tBase = reinterpret_cast<const cf*>(a.tab);
+    }
+    if constexpr (OUTK == 2) {   // colour table into LDS (n_colors <= 256); it is read after the first workgroup barrier of the store phase
+        if (threadIdx.x < 256) s_lut[threadIdx.x] = a.lut[(int)threadIdx.x < a.n_colors ? (int)threadIdx.x : a.n_colors - 1];
+    }
+    cf twA[C::TWF ? U2 : 1], twC = {0.f, 0.f};           // TWF: this lane's constant factors (see Cfg)
+    int twBrow = 0;
+    if constexpr (C::TWF) {
+#pragma unroll
+        for (int v = 0; v < U2; ++v) twA[v] = tBase[C::TAB_A + v * C::TL + tl];
+        twC = tBase[C::TAB_POST + tl];
+        twBrow = C::TAB_TW2 + (ll % R3) * C::TSB;
+    }
+    const cf* const tTw1 = tBase + C::TAB_TW1;       // compact: [n2][TS1], not indexed by lane
+    int tw1row[U1];                                   // row of this lane's butterfly u in the stage-1 table
+#pragma unroll
+    for (int u = 0; u < U1; ++u) tw1row[u] = ((ll + L * u) / R3) * C::TS1;
+    // values j and j + 1 (j even) of this lane from the [J][TL] table at `off`: one 16-byte read (pair layout)
+    auto tab2 = [&](int off, int j, cf& a0, cf& a1) {
+        const v4f q4 = *reinterpret_cast<const v4f*>(tBase + off + C::tab_idx(j, tl));
+        a0 = cf{q4.x, q4.y};
+        a1 = cf{q4.z, q4.w};
+    };
+    // exchange synchronisation: lock-step lanes of one wave need only a compiler fence; frames that span several
+    // waves (L > 64) need the workgroup barrier (every wave of the workgroup runs the same number of them)
+    auto frame_sync = [&]() {
+        if constexpr (L > 64) __syncthreads();
+        else wave_sync();
+    };
+
+    // per-lane LDS element offsets of the two exchanges
+    constexpr bool TWO = C::TWO_STAGE;
+    int e1r[U2], e2w[TWO ? 1 : U2], e2r[TWO ? 1 : U3];
+#pragma unroll
+    for (int v = 0; v < U2; ++v) {
+        const int t2 = ll + L * v;
+        e1r[v] = (t2 / R3) * C::S1 + (t2 % R3);
+        if constexpr (!TWO) e2w[v] = (t2 / R3) * C::AX + (t2 % R3) * C::AZ;
+    }
+    if constexpr (!TWO) {
+#pragma unroll
+        for (int w = 0; w < U3; ++w) {
+            const int t3 = ll + L * w;
+            e2r[w] = (t3 % R1) * C::AX + (t3 / R1) * C::AY;
+        }
+    } else {
+        e2w[0] = e2r[0] = 0;
+    }
+
+    cf acc[F][P / 2];   // .x: bin k = ll + L rho of the lower half, .y: its mirror M - k (filled as pairs by the post pass)
+    float accNy[F];
+    constexpr float init = (MIXOP == 2) ? 1000000.0f : 0.0f;   // reference Spectrogram.cpp:69,78,86
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+#pragma unroll
+        for (int m = 0; m < P / 2; ++m) acc[f][m] = cf{init, init};
+        accNy[f] = init;
+    }
+
+    // One FFT round of the sequence (F frames of one channel): consumes `raw` (loaded one round ago), re-issues it for
+    // round s+1, transforms, accumulates |X|^2 into acc, and after the last channel of a column runs the mix epilogue + ring
+    // store.  `last_tag` (std::true_type): the peeled final round of the wave, which prefetches nothing.  Peeling keeps
+    // the steady-state loop free of the "did the prefetch happen" merge (register moves and a full vmcnt(0)).
+    // Every stage loops over the F frames INSIDE the stage, in one basic block: the scheduler interleaves the frames'
+    // independent chains, and each table value is fetched once for all of them.
+    auto process = [&](int s, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        cf x[F][P];
+        if constexpr (C::ABL == 2) {
+#pragma unroll
+            for (int f = 0; f < F; ++f)
+#pragma unroll
+                for (int m = 0; m < P; ++m) { raw[f][m].x = __int_as_float(0x3f800000 + lane + m + s + f); raw[f][m].y = 0.5f; }
+        }
+        // ---- window multiply ----
+#pragma unroll
+        for (int m = 0; m < P; m += 2) {
+            cf w0, w1;
+            tab2(C::TAB_WIN, m, w0, w1);
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                x[f][m] = to_cf(raw[f][m]) * w0;
+                x[f][m + 1] = to_cf(raw[f][m + 1]) * w1;
+            }
+        }
+        if constexpr (C::ABL == 3) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (s == 0) st1 = __builtin_readcyclecounter();
+        }
+        if (C::ABL != 2 && !LAST) {   // the next round's frames travel while this one is transformed
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const f2u* src = frame_src(s + 1, f);
+#pragma unroll
+                for (int m = 0; m < P; ++m) raw[f][m] = src[L * m];
+            }
+        }
+        if constexpr (C::ABL == 1) {   // ablation: memory traffic only (results are meaningless)
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+#pragma unroll
+                for (int m = 0; m < P / 2; ++m) acc[f][m] += x[f][m] * x[f][m + P / 2].yx;
+                accNy[f] += x[f][0].x;
+            }
+        }
+        if constexpr (C::ABL != 1) {
+        // ---- stage 1: radix-R1 over n1, twiddle W_{R1R2}^{n2 k1}, exchange 1 ----
+#pragma unroll
+        for (int u = 0; u < U1; ++u) {
+            cf t[F][R1];
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+#pragma unroll
+                for (int n1 = 0; n1 < R1; ++n1) t[f][n1] = x[f][u + U1 * n1];
+                dft<R1>(t[f]);
+                lds0[f * C::LDS_ELEMS + ll + L * u] = t[f][0];
+            }
+#pragma unroll
+            for (int k1 = 1; k1 < R1; k1 += 2) {   // row: k1 = 1, 2 | 3, 4 | ... | R1 - 1, (pad)
+                const v4f q4 = *reinterpret_cast<const v4f*>(tTw1 + tw1row[u] + k1 - 1);
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    lds0[f * C::LDS_ELEMS + k1 * C::S1 + ll + L * u] = cmul(t[f][k1], cf{q4.x, q4.y});
+                    if (k1 + 1 < R1) lds0[f * C::LDS_ELEMS + (k1 + 1) * C::S1 + ll + L * u] = cmul(t[f][k1 + 1], cf{q4.z, q4.w});
+                }
+            }
+        }
+        frame_sync();
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int v = 0; v < U2; ++v) {
+                if constexpr (TWO) {   // R3 == 1: the R2 values of a lane are neighbours in its row (S1 even: 16-byte aligned)
+#pragma unroll
+                    for (int n2 = 0; n2 < R2; n2 += 2) {
+                        const v4f q4 = *reinterpret_cast<const v4f*>(lds0 + f * C::LDS_ELEMS + e1r[v] + n2);
+                        x[f][v * R2 + n2] = cf{q4.x, q4.y};
+                        x[f][v * R2 + n2 + 1] = cf{q4.z, q4.w};
+                    }
+                } else {
+#pragma unroll
+                    for (int n2 = 0; n2 < R2; ++n2) x[f][v * R2 + n2] = lds0[f * C::LDS_ELEMS + e1r[v] + n2 * R3];
+                }
+            }
+        frame_sync();
+        // ---- stage 2: radix-R2 over n2, twiddle W_M^{n3 (k1 + R1 k2)}, exchange 2 ----
+#pragma unroll
+        for (int v = 0; v < U2; ++v) {
+            cf t[F][R2];
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+#pragma unroll
+                for (int n2 = 0; n2 < R2; ++n2) t[f][n2] = x[f][v * R2 + n2];
+                dft<R2>(t[f]);
+            }
+            if constexpr (TWO) {   // n3 = 0: the stage-2 twiddle is 1, and Z[ll + L k2] already sits in register k2 of lane ll
+#pragma unroll
+                for (int f = 0; f < F; ++f)
+#pragma unroll
+                    for (int k2 = 0; k2 < R2; ++k2) x[f][v * R2 + k2] = t[f][k2];
+            } else {
+#pragma unroll
+                for (int k2 = 0; k2 < R2; k2 += 2) {
+                    cf w0, w1;
+                    if constexpr (C::TWF) {
+                        const v4f q4 = *reinterpret_cast<const v4f*>(tBase + twBrow + k2);
+                        w0 = cmul(cf{q4.x, q4.y}, twA[v]);
+                        w1 = cmul(cf{q4.z, q4.w}, twA[v]);
+                    } else tab2(C::TAB_TW2, v * R2 + k2, w0, w1);
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        lds0[f * C::LDS_ELEMS + e2w[v] + k2 * C::AY] = cmul(t[f][k2], w0);
+                        lds0[f * C::LDS_ELEMS + e2w[v] + (k2 + 1) * C::AY] = cmul(t[f][k2 + 1], w1);
+                    }
+                }
+            }
+        }
+        if constexpr (!TWO) {
+        frame_sync();
+        // ---- stage 3: radix-R3 over n3; Z[k], k = t3 + R1 R2 k3 ----
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int w = 0; w < U3; ++w) {
+                if constexpr (C::AZ == 1) {
+                    // AZ == 1 (512 points, 4096 "B"): the n3 values of a lane are neighbours, and the IR load/store vectorizer
+                    // (not the backend pass that JSG_NO_LDS_MERGE switches off) pairs them into 16-byte loads of 8-byte
+                    // alignment = ds_read2_b64: 8 LDS cycles instead of 2 x 2, banked differently from what the layout was
+                    // searched for (profile of round 3: 15.7 % of the LDS cycles of the 4096 "B" kernel were bank conflicts).
+                    // The odd n3 are therefore read through a second pointer whose relation to the first the optimizer cannot see.
+                    typedef const cf __attribute__((address_space(3))) * lds_cf_ptr;   // (an LDS pointer: 32 bits, stays a ds_read)
+                    const lds_cf_ptr pe = (lds_cf_ptr)(lds0 + f * C::LDS_ELEMS + e2r[w]);
+                    lds_cf_ptr po = pe + 1;
+                    asm("" : "+v"(po));
+#pragma unroll
+                    for (int n3 = 0; n3 < R3; n3 += 2) {
+                        x[f][w * R3 + n3] = pe[n3];
+                        x[f][w * R3 + n3 + 1] = po[n3];
+                    }
+                } else {
+#pragma unroll
+                    for (int n3 = 0; n3 < R3; ++n3) x[f][w * R3 + n3] = lds0[f * C::LDS_ELEMS + e2r[w] + n3 * C::AZ];
+                }
+            }
+        frame_sync();
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int w = 0; w < U3; ++w) {
+                cf t[R3];
+#pragma unroll
+                for (int n3 = 0; n3 < R3; ++n3) t[n3] = x[f][w * R3 + n3];
+                dft<R3>(t);
+#pragma unroll
+                for (int k3 = 0; k3 < R3; ++k3) x[f][w * R3 + k3] = t[k3];
+            }
+        } else {
+            frame_sync();   // the post pass reuses the exchange buffer: keep its stores behind the exchange-1 loads
+        }
+        {
+            // ---- paired real-split post pass.  Bin k = ll + L*rho (rho = w + U3*k3).  A lane owns the pairs of its
+            // lower registers rho < P/2: (k, M-k); Z[M-k] is the upper register P-1-rho of lane L-ll (lane 0: its own
+            // register P-rho, and Z[M] = Z[0]).  With the window pre-scaled by 1/2 and T = (-i W_N^k) (Z[k] - conj Z[M-k]):
+            //     X[k] = S + T,   X[M-k] = conj(S - T),   S = Z[k] + conj Z[M-k]
+            // The self-paired bin M/2 (lane 0, register rho = P/2) is conj Z[M/2].  acc[j] = (|X[ll + L j]|^2,
+            // |X[M - ll - L j]|^2) (j < P/2), accNy = |X[M/2]|^2.  The two powers of a pair are formed side by side: real parts
+            // (S.x + T.x, S.x - T.x) and imaginary parts of X[k] and X[M-k] in one packed add each, then one packed multiply
+            // and one packed fma give both |.|^2, and the mix accumulates the pair with one packed add.
+            auto reg_of = [](int rho) { return (rho % U3) * R3 + rho / U3; };
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+#pragma unroll
+                for (int rho = P / 2; rho < P; ++rho) lds0[f * C::LDS_ELEMS + ll + L * rho] = x[f][reg_of(rho)];
+                if (ll == 0) lds0[f * C::LDS_ELEMS + M] = x[f][0];   // Z[M] := Z[0]
+            }
+            frame_sync();
+            cf zq[F][P / 2];
+#pragma unroll
+            for (int f = 0; f < F; ++f)
+#pragma unroll
+                for (int rho = 0; rho < P / 2; ++rho) zq[f][rho] = lds0[f * C::LDS_ELEMS + M - (ll + L * rho)];
+            frame_sync();   // the next round's exchange stores must stay behind these loads
+            cf wpost[P / 2];
+#pragma unroll
+            for (int rho = 0; rho < P / 2; rho += 2) {
+                if constexpr (C::TWF) {
+                    constexpr int Q = 64 / (C::N / L);   // W_(N/L)^rho as a multiple of 2 pi / 64
+                    wpost[rho] = cmul_s(twC, cf{kCos64[Q * rho], -kSin64[Q * rho]});
+                    wpost[rho + 1] = cmul_s(twC, cf{kCos64[Q * (rho + 1)], -kSin64[Q * (rho + 1)]});
+                } else tab2(C::TAB_POST, rho, wpost[rho], wpost[rho + 1]);
+            }
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+#pragma unroll
+                for (int rho = 0; rho < P / 2; ++rho) {
+                    const cf z = x[f][reg_of(rho)], p = zq[f][rho];
+                    const cf S = add_conj(z, p);
+                    const cf T = cmul(sub_conj(z, p), wpost[rho]);
+                    const cf re = addsub_re(S, T), im = addsub_im(S, T);   // (Re X[k], Re X[M-k]), (Im X[k], -Im X[M-k])
+                    cf pw = re * re;
+                    pw = __builtin_elementwise_fma(im, im, pw);
+                    acc[f][rho] = mix_combine2<MIXOP>(acc[f][rho], pw);
+                }
+                {   // bin M/2 (held by the frame's lane 0): the window carries 1/2, so |X|^2 = 4 |Z'|^2.  For single-wave
+                    // frames the value is broadcast so that every lane can take part in an unmasked store below.
+                    cf z = x[f][reg_of(P / 2)];
+                    if constexpr (L == 64) {
+                        z.x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(z.x)));
+                        z.y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(z.y)));
+                    } else if constexpr (L == 32) {
+                        const int ax = __builtin_amdgcn_readlane(__float_as_int(z.x), 0), bx = __builtin_amdgcn_readlane(__float_as_int(z.x), 32);
+                        const int ay = __builtin_amdgcn_readlane(__float_as_int(z.y), 0), by = __builtin_amdgcn_readlane(__float_as_int(z.y), 32);
+                        z.x = __int_as_float(sub ? bx : ax);
+                        z.y = __int_as_float(sub ? by : ay);
+                    }
+                    accNy[f] = mix_combine<MIXOP>(accNy[f], 4.0f * (z.x * z.x + z.y * z.y));
+                }
+            }
+        }
+        }   // ABL != 1
+
+        // ---- last channel of this column: mix epilogue + dB + ring store ----
+        const unsigned it = (nc == 1) ? (unsigned)s : (unsigned)s / (unsigned)nc;
+#ifdef JSG_X_NOEPI   // (timing experiment, wrong results) the epilogue only runs for a value that never occurs
+        if ((ONE || s - (int)it * nc == nc - 1) && acc[0][0].x == 12345.678f) {
+#else
+        if (ONE || s - (int)it * nc == nc - 1) {
+#endif
+            if constexpr (C::ABL == 3) { if (s == 0) st2 = __builtin_readcyclecounter(); }
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                unsigned col = a.ring_pos + task_of(it, f);        // n_frames <= ring_w (checked by the launcher)
+                if (col >= (unsigned)a.ring_w) col -= a.ring_w;
+                if constexpr (ONE) {
+                    // one channel: the launcher selects this instantiation only when the mix scale is exactly 1
+                } else
+                if (a.exact_div) {   // m_powerfinal[kk] /= m_channels (Spectrogram.cpp:74), IEEE division
+#pragma unroll
+                    for (int m = 0; m < P / 2; ++m) acc[f][m] = cf{acc[f][m].x / a.divisor, acc[f][m].y / a.divisor};
+                    accNy[f] = accNy[f] / a.divisor;
+                } else if (a.scale != 1.0f) {   // power-of-two channel count: the same division as an exact scaling
+#pragma unroll
+                    for (int m = 0; m < P / 2; ++m) acc[f][m] *= a.scale;
+                    accNy[f] *= a.scale;
+                }
+                if (!a.linear) {
+#pragma unroll
+                    for (int m = 0; m < P / 2; ++m) {   // to_db() of both values of a pair: packed add and multiply around the two v_log
+                        cf t = acc[f][m] + cf{1e-11f, 1e-11f};
+                        t = cf{__builtin_amdgcn_logf(t.x), __builtin_amdgcn_logf(t.y)};
+                        acc[f][m] = t * cf{3.0102999566398120f, 3.0102999566398120f};
+                    }
+                    accNy[f] = to_db(accNy[f]);
+                }
+                if constexpr (L == 32) {
+                    // Two frames sit side by side in the wavefront (lanes 0-31 | 32-63), and register rho of a lane is bin
+                    // ll + 32 rho of ITS frame: stored as they lie, one instruction would write two 128-byte runs, in columns
+                    // whose starts are not 128-byte aligned.  v_permlane32_swap trades the upper half of register rho
+                    // (rho even) against the lower half of register rho + 1: afterwards register rho holds bins
+                    // 32 rho + lane of the lower frame over all 64 lanes and register rho + 1 the same bins of the upper
+                    // frame -- 256 contiguous bytes per store instruction, as in the 64-lane plans.
+#pragma unroll
+                    for (int m = 0; m < P / 2; m += 2) {
+                        const auto lo = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[f][m].x), __float_as_uint(acc[f][m + 1].x), false, false);
+                        const auto hi = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[f][m].y), __float_as_uint(acc[f][m + 1].y), false, false);
+                        acc[f][m] = cf{__uint_as_float(lo[0]), __uint_as_float(hi[0])};
+                        acc[f][m + 1] = cf{__uint_as_float(lo[1]), __uint_as_float(hi[1])};
+                    }
+                }
+                // column of the frame whose bins register rho holds after the swap (L == 32), else this lane's own
+                const unsigned colA = L == 32 ? (unsigned)__builtin_amdgcn_readlane((int)col, 0) : col;
+                const unsigned colB = L == 32 ? (unsigned)__builtin_amdgcn_readlane((int)col, 32) : col;
+                constexpr int LW = L == 32 ? 64 : L;         // lanes that share one store instruction's run
+                const int lw = L == 32 ? lane : ll;
+                if constexpr (OUTK == 2) {
+                    // palette indices of the column, four to a dword, into this wave's exchange region: dword (r4, ll) of the lower
+                    // half holds bins ll + 64 (4 r4 + j), j = 0..3, the upper half M - those; the region is skewed per wave so that
+                    // the store phase below reads without bank conflicts (eight columns x eight consecutive ll per instruction)
+                    constexpr int D = C::LDS_ELEMS * 2;                       // dwords between the waves' regions
+                    constexpr int SK = ((4 - D % 32) + 32) % 32;              // skew per wave: (D + SK) == 4 (mod 32)
+                    unsigned* ix = reinterpret_cast<unsigned*>(lds0 + f * C::LDS_ELEMS) + (SK * wave) % 32;
+#pragma unroll
+                    for (int r4 = 0; r4 < P / 8; ++r4) {
+                        unsigned wx = 0, wy = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            wx |= (unsigned)color_index(acc[f][4 * r4 + j].x, a.vmin, a.vmax, a.top, a.mult, a.n_colors) << (8 * j);
+                            wy |= (unsigned)color_index(acc[f][4 * r4 + j].y, a.vmin, a.vmax, a.top, a.mult, a.n_colors) << (8 * j);
+                        }
+                        ix[r4 * 64 + ll] = wx;
+                        ix[(P / 8 + r4) * 64 + ll] = wy;
+                    }
+                    if (ll == 0) ix[(P / 4) * 64] = (unsigned)color_index(accNy[f], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
+                    __syncthreads();
+                    {
+                        // ---- store phase: every wave-instruction covers 8 consecutive values of ll (rows) x the 8 columns of the
+                        //      iteration: lane = 8 * dl + c reads dword (h, r4, 8 g + dl) of column c and writes four pixels ----
+                        const int c = lane & 7, dl = lane >> 3;
+                        static_assert(C::TPB == 8 && C::WPB == 8, "the store phase is laid out for eight columns per iteration");
+                        const unsigned tcol = task0 - slot0 + it * task_stride + c;   // column c of this iteration (task0 holds this wave's slot)
+                        const bool live = tcol < a.n_frames;
+                        const unsigned* cx = reinterpret_cast<const unsigned*>(smem_raw) + c * D + (SK * c) % 32;
+                        unsigned x = (unsigned)a.x_first + tcol;
+                        x %= (unsigned)a.x_wrap;
+                        unsigned* const img = a.argb + x;
+                        constexpr int ITEMS = 2 * (P / 8) * 8;               // (half, r4, group of eight ll)
+                        for (int q = wave; q < ITEMS; q += C::WPB) {
+                            const int g = q & 7, hr = q >> 3;                // hr = h * (P / 8) + r4
+                            const int r4 = hr % (P / 8);
+                            const bool upper = hr >= P / 8;
+                            const unsigned w4 = cx[hr * 64 + 8 * g + dl];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int k = 8 * g + dl + 64 * (4 * r4 + j);
+                                const int bin = upper ? M - k : k;
+                                const int rgb = s_lut[(w4 >> (8 * j)) & 0xffu];
+                                // y = H - 1 - bin (Spectrogram.cpp:642).  Plain stores on purpose: a wave-instruction writes 32-byte pieces of eight
+                                // image rows, and the neighbouring workgroups (same XCD: the block remap gives an XCD one contiguous column
+                                // range) write the rest of those 128-byte lines; with the default policy the pieces meet in L2 and leave as
+                                // whole lines, streamed out (non-temporal) every piece went to memory alone: 28.6 vs 22.3 us per C5 image
+                                if (live) img[(long long)(M - bin) * a.argb_pitch] = (unsigned)rgb | 0xFF000000u;
+                            }
+                        }
+                        if (wave == C::WPB - 1 && dl == 0 && live) {     // bin M / 2 of the eight columns
+                            const int rgb = s_lut[cx[(P / 4) * 64] & 0xffu];
+                            img[(long long)(M - M / 2) * a.argb_pitch] = (unsigned)rgb | 0xFF000000u;
+                        }
+                    }
+                    __syncthreads();   // the next round's exchange stores stay behind the reads of the store phase
+                } else if constexpr (OUTK == 1) {
+                    // palette index of every bin; 64 consecutive bytes of the index column per store instruction
+                    unsigned char* icA = a.idx + (long long)colA * a.idx_pitch;
+                    unsigned char* icB = a.idx + (long long)colB * a.idx_pitch;
+                    unsigned char* ic = a.idx + (long long)col * a.idx_pitch;
+#pragma unroll
+                    for (int rho = 0; rho < P / 2; ++rho) {
+                        unsigned char* d = (L == 32 && (rho & 1)) ? icB : icA;
+                        const int k = lw + LW * (L == 32 ? rho / 2 : rho);
+                        d[k] = (unsigned char)color_index(acc[f][rho].x, a.vmin, a.vmax, a.top, a.mult, a.n_colors);
+                        d[M - k] = (unsigned char)color_index(acc[f][rho].y, a.vmin, a.vmax, a.top, a.mult, a.n_colors);
+                    }
+                    if (L <= 64 || ll == 0) ic[M / 2] = (unsigned char)color_index(accNy[f], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
+                } else if (C::ABL == 2 ? (acc[f][0].x == 12345.678f) : true) {
+                    // non-temporal dword stores, 256 contiguous bytes of the column per instruction (streaming the columns out
+                    // instead of leaving them dirty in L2 removed the end-of-kernel write-back)
+                    const long long cofs = a.per_channel ? (long long)c0 * a.out_cpitch : 0ll;
+                    float* dstA = a.out + (long long)colA * a.out_pitch + cofs;
+                    float* dstB = a.out + (long long)colB * a.out_pitch + cofs;
+                    float* dst = a.out + (long long)col * a.out_pitch + cofs;
+#pragma unroll
+                    for (int rho = 0; rho < P / 2; ++rho) {
+                        float* d = (L == 32 && (rho & 1)) ? dstB : dstA;
+                        const int k = lw + LW * (L == 32 ? rho / 2 : rho);
+                        __builtin_nontemporal_store(acc[f][rho].x, &d[k]);
+                        __builtin_nontemporal_store(acc[f][rho].y, &d[M - k]);
+                    }
+                    if (L <= 64 || ll == 0) __builtin_nontemporal_store(accNy[f], &dst[M / 2]);   // L <= 64: uniform over the frame's lanes
+                }
+#pragma unroll
+                for (int m = 0; m < P / 2; ++m) acc[f][m] = cf{init, init};
+                accNy[f] = init;
+            }
+        }
+    };
+
+    for (int s = 0; s + 1 < n_fft; ++s) process(s, std::false_type{});
+    process(n_fft - 1, std::true_type{});
+    if constexpr (C::ABL == 3) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st3 = __builtin_readcyclecounter();
+        if (lane == 0 && a.stamps) {
+            unsigned long long* d = a.stamps + (size_t)(blockIdx.x * C::WPB + wave) * 10;
+            d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3; d[4] = rt0; d[5] = __builtin_amdgcn_s_memrealtime();
+            d[6] = stA; d[7] = 0; d[8] = stC; d[9] = stP;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// plan: window + twiddle tables, laid out [table][register j][lane]
+// ------------------------------------------------------------------------------------------------------------
+template <class C>
+void fill_tables(std::vector<float2>& t, const float* window, double amp) {
+    constexpr int L = C::L, P = C::P, R1 = C::R1, R2 = C::R2, R3 = C::R3, M = C::M, N = C::N, TL = C::TL;
+    t.assign(size_t(C::TAB_ELEMS), make_float2(0.f, 0.f));
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int n2 = 0; n2 < R2; ++n2)   // stage-1 twiddles, one row per n2 (shared by the lanes with t1 / R3 == n2)
+        for (int k1 = 0; k1 < R1; ++k1) {
+            const double ang = -two_pi * double((long long)n2 * k1 % (R1 * R2)) / double(R1 * R2);
+            if (k1 == 0) continue;   // the twiddle of k1 = 0 is 1 and never read; k1 sits at column k1 - 1
+            t[C::TAB_TW1 + n2 * C::TS1 + k1 - 1] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
+        }
+    if constexpr (C::TWF)
+        for (int n3 = 0; n3 < R3; ++n3)
+            for (int k2 = 0; k2 < R2; ++k2) {
+                const double ang = -two_pi * double((long long)n3 * k2 % (M / R1)) / double(M / R1);
+                t[C::TAB_TW2 + n3 * C::TSB + k2] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
+            }
+    for (int e = 0; e < TL; ++e) {   // entry e of a table row belongs to lane-in-frame ll (L = 32: both half-waves)
+        const int ll = e % L;
+        for (int m = 0; m < P; ++m) {   // window pairs: samples 2n, 2n+1 with n = ll + L m
+            const int n = ll + L * m;
+            const double a2 = 0.5 * amp;   // the paired post pass expects Z/2
+            t[C::TAB_WIN + C::tab_idx(m, e)] = make_float2(float(double(window[2 * n]) * a2), float(double(window[2 * n + 1]) * a2));
+        }
+        if constexpr (C::TWF) {   // lane constants A[v] = W_M^(n3 k1), C = -i W_N^ll (the shared B rows are filled above)
+            for (int v = 0; v < C::U2; ++v) {
+                const int t2 = ll + L * v, k1 = t2 / R3, n3 = t2 % R3;
+                const double ang = -two_pi * double((long long)n3 * k1 % M) / double(M);
+                t[C::TAB_A + v * TL + e] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
+            }
+            const double angc = -two_pi * double(ll) / double(N);
+            t[C::TAB_POST + e] = make_float2(float(std::sin(angc)), float(-std::cos(angc)));
+            continue;
+        }
+        for (int v = 0; v < (C::TWO_STAGE ? 0 : C::U2); ++v)
+            for (int k2 = 0; k2 < R2; ++k2) {
+                const int t2 = ll + L * v, k1 = t2 / R3, n3 = t2 % R3;
+                const double ang = -two_pi * double((long long)n3 * (k1 + R1 * k2) % M) / double(M);
+                t[C::TAB_TW2 + C::tab_idx(v * R2 + k2, e)] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
+            }
+        for (int rho = 0; rho < P / 2; ++rho) {   // bins k = ll + L rho of the lower half: -i exp(i ang) = sin(ang) - i cos(ang)
+            const double ang = -two_pi * double(ll + L * rho) / double(N);
+            t[C::TAB_POST + C::tab_idx(rho, e)] = make_float2(float(std::sin(ang)), float(-std::cos(ang)));
+        }
+    }
+}
+
+// Kernels that need more than 48 KB of dynamic LDS must be told so once per device.  jsg_plan_create does it for every
+// instantiation of the plan's size (so that the first launch may already sit inside a stream capture); the launch path
+// repeats the check for plans that are used on a device other than the one they were created on.
+template <class C, int MIXOP, int OUTK>
+hipError_t ensure_lds_attr() {
+    static std::atomic<bool> attr_done[64];   // set once per device; setting it twice from two threads is harmless
+    if (C::LDS_BYTES <= 48 * 1024) return hipSuccess;
+    int dev = 0;
+    hipError_t err = hipGetDevice(&dev);
+    if (err != hipSuccess) return err;
+    if (dev >= 0 && dev < 64 && !attr_done[dev].load(std::memory_order_acquire)) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_db_kernel<C, MIXOP, OUTK>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (err != hipSuccess) return err;
+        attr_done[dev].store(true, std::memory_order_release);
+    }
+    return hipSuccess;
+}
+
+// plans that can colour their own columns (stft_db_kernel, OUTK == 2): one wavefront per frame, eight frames per workgroup
+template <class C>
+constexpr bool image_ok = C::L == 64 && C::FPW == 1 && C::TPB == 8 && C::WPB == 8 && C::LDS_TOTAL + 1024 <= 160 * 1024;
+
+template <class C>
+hipError_t ensure_lds_attrs_of_plan() {
+    hipError_t e = ensure_lds_attr<C, 0, 0>();
+    if (e == hipSuccess) e = ensure_lds_attr<C, 1, 0>();
+    if (e == hipSuccess) e = ensure_lds_attr<C, 2, 0>();
+    if (e == hipSuccess) e = ensure_lds_attr<C, 3, 0>();
+    if (e == hipSuccess) e = ensure_lds_attr<C, 0, 1>();
+    if (e == hipSuccess) e = ensure_lds_attr<C, 3, 1>();
+    if constexpr (image_ok<C>) {
+        if (e == hipSuccess) e = ensure_lds_attr<C, 0, 2>();
+        if (e == hipSuccess) e = ensure_lds_attr<C, 3, 2>();
+    }
+    return e;
+}
+
+template <class C, int MIXOP, int OUTK = 0>
+hipError_t launch_stft_mix(const StftKArgs& ka, dim3 grid, hipStream_t s) {
+    hipError_t err = ensure_lds_attr<C, MIXOP, OUTK>();
+    if (err != hipSuccess) return err;
+    const int flags = (ka.regular ? 1 : 0) | (ka.per_channel ? 2 : 0) | (ka.xcd_remap ? 4 : 0) | (ka.chunked ? 8 : 0);
+    hipLaunchKernelGGL((stft_db_kernel<C, MIXOP, OUTK>), grid, dim3(C::WPB * 64), C::LDS_BYTES, s, ka.in, ka.in_pitch, ka.tab, ka.n_frames,
+                       ka.first_frame, ka.hop, flags, unsigned(ka.c_begin) | unsigned(ka.c_end) << 16, ka.iters, grid.x, ka.feedblocks, ka);
+    return hipGetLastError();
+}
+
+template <class C>
+hipError_t launch_stft(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s) {
+    if (ka.argb) {  // single-kernel display path
+        if constexpr (image_ok<C>) {
+            if (mixop == 3) return launch_stft_mix<C, 3, 2>(ka, grid, s);
+            if (mixop == 0) return launch_stft_mix<C, 0, 2>(ka, grid, s);
+        }
+        return hipErrorInvalidValue;
+    }
+    if (ka.idx) {   // fused display path: the mixed (AbsMean / Sum) and the one-channel instantiations only
+        if (mixop == 3) return launch_stft_mix<C, 3, 1>(ka, grid, s);
+        if (mixop == 0) return launch_stft_mix<C, 0, 1>(ka, grid, s);
+        return hipErrorInvalidValue;
+    }
+    switch (mixop) {
+        case 1: return launch_stft_mix<C, 1>(ka, grid, s);
+        case 2: return launch_stft_mix<C, 2>(ka, grid, s);
+        case 3: return launch_stft_mix<C, 3>(ka, grid, s);
+        default: return launch_stft_mix<C, 0>(ka, grid, s);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Per-plan entry points.  The kernels of a plan are instantiated in exactly one translation unit (jsg_stft_a.hip or
+// jsg_stft_b.hip: JSG_STFT_PLANS below); jsg_kernels.hip reaches them through these plain functions only, so no kernel is
+// ever compiled twice and hipFuncSetAttribute always addresses the one copy that is launched.
+// ------------------------------------------------------------------------------------------------------------
+#define JSG_FOR_EACH_PLAN(X) X(Cfg512) X(Cfg1024) X(Cfg2048) X(Cfg2048B) X(Cfg4096) X(Cfg4096B) X(Cfg8192)
+#define JSG_DECLARE_PLAN(C)                                                                   \
+    hipError_t launch_##C(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s);          \
+    hipError_t ensure_attrs_##C();
+JSG_FOR_EACH_PLAN(JSG_DECLARE_PLAN)
+#undef JSG_DECLARE_PLAN
+#define JSG_DEFINE_PLAN(C)                                                                                                  \
+    hipError_t launch_##C(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s) { return launch_stft<C>(ka, mixop, grid, s); } \
+    hipError_t ensure_attrs_##C() { return ensure_lds_attrs_of_plan<C>(); }
+// Loads the unit's code object onto the current device (the runtime loads lazily, 2.5 ms on first use: done when a plan is
+// created, not inside the audio thread's first jsg_process_block).
+hipError_t touch_module_a();
+hipError_t touch_module_b();
+
+}  // namespace jsg
