@@ -97,6 +97,19 @@ def _cpu_model() -> str:
     return "unknown"
 
 
+def kernel_source_sha() -> str:
+    """Hash of the sources the kernels are built from (csrc/ + include/jsg.h + the build flags in _build.py): a profile under
+    profiles/ describes this build exactly when it carries the same hash, whatever was committed in between."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "jadespectrogram_amd")
+    files = sorted(os.path.join(base, "csrc", f) for f in os.listdir(os.path.join(base, "csrc"))) + [os.path.join(base, "_build.py"),
+                                                                                                       os.path.join(ROOT, "include", "jsg.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _git_commit() -> str:
     try:
         return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
@@ -156,6 +169,23 @@ def cpu_baseline(c, seconds_budget: float = 10.0):
         res["all_cores"] = {"value": v2, "unit": c["unit"], "cores": cores,
                             "sample": f"median of {k2} passes, OpenMP over columns, plan and buffers reused across passes"}
     return res
+
+
+# Vector instructions per FFT of the kernels the configurations time (SQ_INSTS_VALU / FFTs, profiles/r03_*_pmc.json) and the clock
+# the counters imply under that load: the issue roof of the compute-bound configurations (a wave64 VALU instruction holds its
+# SIMD for 4 cycles; 256 CUs x 4 SIMDs).
+VALU_PER_FFT = {"c2": 221.0, "c3": 386.0, "c5": 1150.0}
+CLOCK_GHZ_UNDER_LOAD = 1.9
+
+
+def valu_roof(c, units_per_launch, inorder_us):
+    key = {1024: "c2", 2048: "c3", 4096: "c5"}[c["n"]]
+    ffts = units_per_launch * (c["channels"] if c["colour"] else 1)
+    roof = 1024 * CLOCK_GHZ_UNDER_LOAD * 1e9 / (4.0 * VALU_PER_FFT[key])          # FFT/s with every SIMD issuing every cycle
+    got = ffts / (inorder_us * 1e-6)
+    return {"bound": "valu_issue", "achieved": got, "peak": roof, "unit": "FFT/s", "frac": got / roof,
+            "note": f"{VALU_PER_FFT[key]:.0f} vector instructions per FFT (PMC) x 4 cycles on 1024 SIMDs at ~{CLOCK_GHZ_UNDER_LOAD} GHz under load; "
+                    "C3 and C5 are bound here, not by HBM (DESIGN.md section 6)"}
 
 
 def boundary_latency_subprocess():
@@ -452,7 +482,22 @@ def main():
                 with torch.cuda.stream(one):
                     graph.replay()
 
-        if n_streams > 1 and c["colour"]:
+        if n_streams > 1 and c["colour"] and args.no_graph:
+            # ---- the same independent images, host-issued round-robin over the streams (for the tracer: it does not see kernels
+            #      inside graph replays); --gate holds every stream while the host enqueues the step ----
+            streams = [torch.cuda.Stream() for _ in range(n_streams)]
+
+            def run_step():
+                if args.gate and gate["cycles"]:
+                    for st in streams:
+                        with torch.cuda.stream(st):
+                            torch.cuda._sleep(gate["cycles"])
+                t_i = time.perf_counter()
+                for i in range(lps):
+                    launch(i % nbuf, streams[i % n_streams].cuda_stream)
+                if args.gate:
+                    gate["cycles"] = int(min(500.0, 1.5 * (time.perf_counter() - t_i) * 1e3 + 0.2) * gate["cycles_per_ms"])
+        elif n_streams > 1 and c["colour"]:
             # ---- independent images on n_streams streams: one hipGraph per stream (image i goes to stream i % n_streams, so a
             #      batch's scratch and image are always rewritten in order), replayed together: the colour kernel of one image
             #      runs beside the STFT kernel of the next ----
@@ -606,19 +651,33 @@ def main():
     if inorder_us:
         achieved = algo / (inorder_us * 1e-6) / 1e9
         conc = algo * lps * args.steps / wall / 1e9
-        traffic, tsrc = None, None
-        prof = os.path.join(ROOT, "profiles", f"r02_{args.config}_hbm_traffic.json")
+        # HBM traffic (PMC) and the tracer's per-dispatch duration come from the rocprofv3 passes of tools/profile_bench.sh
+        # (profiles/r03_<cfg>_hbm_traffic.json): bench.py does not run counters itself.  The file carries the hash of the kernel
+        # sources it was recorded with; when that differs from this build's the figures are flagged as stale and `frac` falls back
+        # to this run's own event timing.
+        traffic, tsrc, rocprof_us = None, None, None
+        prof = os.path.join(ROOT, "profiles", f"r03_{args.config}_hbm_traffic.json")
         if os.path.exists(prof):
             try:
                 pj = json.load(open(prof))
+                same = pj.get("kernel_source_sha") == kernel_source_sha()
                 traffic = pj.get("hbm_bytes_per_launch")
-                tsrc = {"file": os.path.relpath(prof, ROOT), "recorded_at_commit": pj.get("commit"), "rocprof_avg_dispatch_us": pj.get("avg_us"),
-                        "note": "PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE) recorded earlier with rocprofv3; NOT measured by this run"}
+                rocprof_us = pj.get("avg_us") if same else None
+                tsrc = {"file": os.path.relpath(prof, ROOT), "recorded_at_commit": pj.get("commit"), "kernel_source_sha": pj.get("kernel_source_sha"),
+                        "matches_this_build": same, "rocprof_avg_dispatch_us": pj.get("avg_us"),
+                        "note": "rocprofv3 passes of tools/profile_bench.sh (kernel trace; FETCH_SIZE x2 on gfx950 + WRITE_SIZE in separate PMC passes), "
+                                "recorded earlier; NOT measured by this run" + ("" if same else " -- STALE: the kernel sources have changed since")}
             except Exception:
                 traffic = None
+        frac_events = achieved / HBM_PEAK_GBS
+        frac_rocprof = (algo / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rocprof_us else None
         out["roofline"] = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "frac_of_8p0": achieved / HBM_PEAK_GBS, "frac_of_6p3": achieved / HBM_ACHIEVABLE_GBS,
+            "bound": "hbm", "achieved": (frac_rocprof or frac_events) * HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": frac_rocprof or frac_events,
+            "frac_source": ("rocprofv3 per-dispatch average of the same in-order launches (profiles/, same kernel sources)" if frac_rocprof
+                            else "this run's HIP events (no matching rocprofv3 profile under profiles/)"),
+            "frac_event_timed": frac_events, "frac_rocprof": frac_rocprof,
+            "frac_of_8p0": frac_rocprof or frac_events, "frac_of_6p3": (frac_rocprof or frac_events) * HBM_PEAK_GBS / HBM_ACHIEVABLE_GBS,
             "traffic": traffic, "traffic_source": tsrc,
             "kernel": (kernel_label if c["colour"] else f"stft_db_kernel<{(parity or {}).get('kernel', n)}>"),
             "avg_launch_us": inorder_us, "avg_launch_us_host_issued": eager_us,
@@ -628,6 +687,7 @@ def main():
             "note": "achieved/frac: per-kernel view (in order, one stream); timed_region_*: algorithmic bytes of the K timed steps / their wall "
                     "time (independent launches overlapped on hip_streams_per_gpu streams)",
             "memcpy_same_bytes_us": copy_us, "frac_of_memcpy_rate": (copy_us / inorder_us) if copy_us else None,
+            "second_roof": valu_roof(c, units_per_launch, inorder_us),
             "commit": commit,
         }
     if parity is not None:

@@ -6,7 +6,7 @@
 #   3. one SQ counter pass
 # Summaries are post-processed by tools/profile_summarize.py into gpurun_out/profiles_<tag>/ (copy them to profiles/).
 set -u
-TAG=${1:-r02}; CFG=${2:-c2}
+TAG=${1:-r03}; CFG=${2:-c2}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_bench_${TAG}_${CFG}
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 # inside hipGraph replays -- its counter passes crash on them), so the per-dispatch duration is the per-kernel number
 # that bench.py's `roofline` reports; the driver-shaped step counts are used as they are
 GATE=""; [ "$CFG" = c2 ] && GATE="--gate"     # short kernels: keep the traced dispatches back to back (bench.py --gate)
-CMD="python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --streams 1 --no-graph $GATE --steps 20 --warmup 5 --no-cpu-baseline"
+CMD="python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --streams 1 --no-graph $GATE --steps 20 --warmup 5 --no-cpu-baseline --no-boundary"
 # counter passes: the same launches, fewer of them (the collector serialises every dispatch, and crashed on the 25 000
 # queued dispatches of the full-size command); counters are per-dispatch means, so the count does not matter
 PMC_CMD="$CMD --launches-per-step 32 --steps 10 --warmup 2"

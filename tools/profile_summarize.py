@@ -13,6 +13,7 @@ try:
     res["commit"] = json.load(open(os.path.join(root, "jadespectrogram_amd", "_build_info.json"))).get("commit")
 except Exception:
     res["commit"] = None
+res["kernel_source_sha"] = bench.kernel_source_sha()   # bench.py trusts these figures only for a build with the same hash
 # the bench line printed under the tracer (its in-order number must agree with the tracer's average)
 try:
     line = json.loads(open(os.path.join(out_dir, "bench_lines.jsonl")).readline())
@@ -32,7 +33,7 @@ for f in glob.glob(os.path.join(out_dir, "stats", "**", "*kernel_stats.csv"), re
     res["kernels"] = {}
     for r in rows:
         for key in ("stft_db_kernel", "colormap_kernel"):
-            if key in r["Name"] and (key not in res["kernels"] or int(r["Calls"]) > res["kernels"][key]["calls"]):   # the bench's own instantiation
+            if key in r["Name"] and "spin_kernel" not in r["Name"] and (key not in res["kernels"] or int(r["Calls"]) > res["kernels"][key]["calls"]):   # the bench's own instantiation
                 res["kernels"][key] = {"name": r["Name"][:120], "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                                        "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3}
     if main_kernel in res["kernels"]:
