@@ -45,10 +45,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues per device (default 4, read when the runtime
-# loads) and torch's own streams take part in that round-robin: with the default, two of the bench's four busy streams can
-# land on ONE hardware queue and serialise (measured: 1.13-1.19e9 frames/s), with eight queues every busy stream has its
-# own (1.32e9).  More than four BUSY queues is what to avoid (5+ streams on 8 queues: 0.5-0.8e9) -- see tools/sweep_overlap.sh.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# starts) in creation order, and torch's own streams take part: with too few queues two of the bench's busy streams land on ONE
+# hardware queue and serialise (round 3, nine streams in the process: 0.79 / 0.41 / 0.84 / 1.08 / 1.08e9 frames/s at 4 / 6 / 8 / 12 /
+# 16 queues).  What must stay at four is the number of BUSY queues (a fifth makes the command processor time-slice: 0.35e9).
+if not os.environ.get("JSG_KEEP_HW_QUEUES"):      # (libjsg.so applies the same default when it is loaded before the HIP runtime starts)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROTATION_BYTES = 1.0e9       # distinct input + output bytes the timed launches rotate over (>> 256 MiB Infinity Cache)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -316,6 +317,7 @@ def main():
     ap.add_argument("--issue-threads", type=int, default=2, help="host threads issuing the launches of a step (c2, streams > 1)")
     ap.add_argument("--blocks-per-cu", type=int, default=1, help="workgroups per CU of each launch when launches overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sub-run", action="store_true", help="(internal) this process is the default-environment child of another bench.py")
     ap.add_argument("--no-boundary", action="store_true", help="skip the `boundary` block (jsg_process_block latency, PCIe-inclusive rate)")
     ap.add_argument("--gate", action="store_true", help="with --no-graph: hold the stream with a gate kernel while the host enqueues a step's "
                                                         "launches, so that they run back to back even under a tracer (short kernels: c2)")
@@ -338,6 +340,20 @@ def main():
     if not args.dry_run and not args.no_cpu_baseline and world == 1:   # the CPU baseline leg runs at N = 1 only
         from oracle import oracle_c
         oracle_c.load()
+    default_env = None
+    if not args.dry_run and not args.no_boundary and world == 1 and not args.sub_run and not c["colour"] and not args.streams:
+        # the same timed region in a child process WITHOUT the eight hardware queues (GPU_MAX_HW_QUEUES unset, the library told to keep
+        # its hands off): what a host sees that neither sets the variable nor loads libjsg.so before the HIP runtime starts
+        env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+        env["JSG_KEEP_HW_QUEUES"] = "1"
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", args.config, "--steps", "10", "--warmup", "3", "--no-cpu-baseline",
+                                "--no-boundary", "--sub-run"], env=env, capture_output=True, text=True, timeout=300)
+            sl = json.loads(r.stdout.strip().splitlines()[-1])
+            default_env = {"GPU_MAX_HW_QUEUES": "unset (runtime default 4)", "value": sl["value"], "unit": sl["unit"],
+                           "timed_region_frac_of_8p0": sl["roofline"]["timed_region_frac_of_8p0"], "steps": 10}
+        except Exception as e:
+            default_env = {"error": f"{type(e).__name__}: {e}"[:200]}
     boundary = None
     if not args.dry_run and not args.no_boundary and world == 1:
         boundary = {"process_block_latency": boundary_latency_subprocess()}
@@ -525,8 +541,12 @@ def main():
                 ctypes.memmove(ctypes.byref(arr, i * ctypes.sizeof(capi.StftArgs)), ctypes.byref(a_i), ctypes.sizeof(capi.StftArgs))
             streams = [torch.cuda.Stream() for _ in range(n_streams)]
             sarr = (ctypes.c_void_p * n_streams)(*[st.cuda_stream for st in streams])
+            use_pool = not args.streams and not args.gate    # default: the LIBRARY's launch pool (its own streams and issuing threads)
 
             def run_step():
+                if use_pool:
+                    capi.check(lib.jsg_stft_db_launch_batches(plan._p, arr, lps, ctypes.c_void_p(one.cuda_stream)))
+                    return
                 # --gate (for the tracer, tools/profile_overlap.sh): every stream is held by a bounded spin kernel while the host
                 # enqueues the step, so the launches overlap on the GPU exactly as they do when the host keeps up
                 if args.gate and gate["cycles"]:
@@ -642,7 +662,7 @@ def main():
                    "step": f"{lps} launches x {F} {'columns' if c['colour'] or C > 1 else 'frames'} = {lps * units_per_launch} {c['unit'].split('/')[0]} per step and GPU",
                    "launches_per_step": lps, "frames_per_launch": F * C, "columns_per_launch": F, "channels_per_gpu": C,
                    "distinct_batches": nbuf, "hip_streams_per_gpu": n_streams, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
-                   "issue": ((("host-issued behind a gate kernel, in order and back to back on one stream (the gate is inside the timed region: this mode is for the tracer)" if args.gate else "host-issued, in order on one stream") if args.no_graph else "hipGraph replay, in order") if n_streams == 1 else (f"{n_streams} hipGraphs per step (independent images, one stream each), replayed together" if c["colour"] else f"one C call per step, {max(1, args.issue_threads)} host thread(s)" + (", every stream held by a gate kernel while the host enqueues the step (the gates are inside the timed region: this mode is for the tracer)" if args.gate else ""))),
+                   "issue": ((("host-issued behind a gate kernel, in order and back to back on one stream (the gate is inside the timed region: this mode is for the tracer)" if args.gate else "host-issued, in order on one stream") if args.no_graph else "hipGraph replay, in order") if n_streams == 1 else (f"{n_streams} hipGraphs per step (independent images, one stream each), replayed together" if c["colour"] else ("one jsg_stft_db_launch_batches call per step on one caller stream: the library forks onto its own streams (4; 2 for the one-workgroup-per-CU kernels), issues from 2 host threads and joins" if (not args.streams and not args.gate) else f"one C call per step, {max(1, args.issue_threads)} host thread(s)") + (", every stream held by a gate kernel while the host enqueues the step (the gates are inside the timed region: this mode is for the tracer)" if args.gate else ""))),
                    "prewarm_s": round(prewarm_s, 3),
                    "parallelism": f"{world} GPU(s), independent batches, no data-path collective"},
     }
@@ -692,6 +712,8 @@ def main():
         }
     if parity is not None:
         out["parity"] = parity
+    if default_env is not None:
+        out["config"]["same_region_default_environment"] = default_env
     if boundary is not None and rank == 0:
         boundary["pcie_inclusive_rate"] = boundary_pcie_rate(jsg, c)
         out["boundary"] = boundary

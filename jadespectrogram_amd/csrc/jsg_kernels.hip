@@ -65,7 +65,10 @@ constexpr int CM_TILE = 64;   // 64 columns x 64 bins per workgroup
 
 __global__ __launch_bounds__(256) void colormap_kernel(const CmapKArgs a) {
     __shared__ int s_lut[1024];
-    __shared__ unsigned short s_idx[CM_TILE][CM_TILE + 2];   // [bin][col]
+    // [bin][col], one dword per pixel and a row stride of 65 dwords: the column-wise writes of the read phase and the row-wise reads
+    // of the write phase both touch 32 different banks per half-wave (as 16-bit pairs, round 2, a third of this kernel's LDS
+    // cycles were bank conflicts: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.33)
+    __shared__ int s_idx[CM_TILE][CM_TILE + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool lut_in_lds = a.n_colors <= 1024;
 
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256) void colormap_kernel(const CmapKArgs a) {
         if (lut_in_lds)
             for (int k = tid; k < a.n_colors; k += 256) s_lut[k] = a.lut[k];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) s_idx[tb + k][tc] = (unsigned short)((w[k >> 2] >> (8 * (k & 3))) & 0xffu);
+        for (int k = 0; k < 16; ++k) s_idx[tb + k][tc] = (int)((w[k >> 2] >> (8 * (k & 3))) & 0xffu);
     } else {
         float v[CM_TILE / 4];
 #pragma unroll
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(256) void colormap_kernel(const CmapKArgs a) {
             for (int i = tid; i < a.n_colors; i += 256) s_lut[i] = a.lut[i];
 #pragma unroll
         for (int q = 0; q < CM_TILE / 4; ++q)
-            s_idx[lane][wave + 4 * q] = (unsigned short)color_index(v[q], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
+            s_idx[lane][wave + 4 * q] = color_index(v[q], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
     }
     __syncthreads();
     // write phase: each wave takes 16 image rows; lane = column (256 B coalesced per row when x does not wrap)
@@ -595,17 +598,20 @@ int jsg_stft_db_launch_many_threads(const jsg_plan* plan, const jsg_stft_args* a
     return JSG_OK;
 }
 
-// ---- the library's own launch pool: four streams per device, fork / join against the caller's stream ----
+// ---- the library's own launch pool: the caller's stream plus three streams of the library, fork / join against the caller's stream ----
+// The compute front end of the GPU runs four hardware queues at a time: with a fifth BUSY queue the command processor time-slices them
+// and the rate collapses (measured, C2: 1.08e9 frames/s with four busy queues, 0.35e9 with five).  The caller's own stream is therefore one
+// of the four working streams -- it would be busy anyway with the fork and join events -- and not a fifth one beside them.
 namespace {
 struct LaunchPool {
     std::mutex mu;                 // one call at a time per device (the fork / join events are reused)
     bool ready = false;
-    hipStream_t s[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t fork = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t s[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
 };
 LaunchPool g_pools[64];
-constexpr int kPoolStreams = 4;    // measured: 3 streams 1.25e9, 4 streams 1.32e9, 5 and more 0.5-0.8e9 frames/s at C2 (tools/sweep_overlap.sh)
-constexpr int kPoolThreads = 2;    // one host thread issues a launch every ~3.5 us, the GPU finishes one every ~3.1 us
+constexpr int kPoolStreams = 4;    // working streams (the caller's + 3): 3 streams 1.25e9, 4 streams 1.32e9, 5 and more 0.5-0.8e9 frames/s at C2 (round 2)
+constexpr int kPoolThreads = 2;    // one host thread issues a launch every ~3.5 us, the GPU finishes one every ~3.1-3.9 us
 }  // namespace
 
 int jsg_stft_db_launch_batches(const jsg_plan* plan, const jsg_stft_args* args, int count, void* stream) {
@@ -619,7 +625,7 @@ int jsg_stft_db_launch_batches(const jsg_plan* plan, const jsg_stft_args* args, 
     std::lock_guard<std::mutex> lk(p.mu);
     hipError_t err = hipSuccess;
     if (!p.ready) {
-        for (int i = 0; i < kPoolStreams && err == hipSuccess; ++i) {
+        for (int i = 0; i < 3 && err == hipSuccess; ++i) {
             err = hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking);
             if (err == hipSuccess) err = hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming);
         }
@@ -629,16 +635,21 @@ int jsg_stft_db_launch_batches(const jsg_plan* plan, const jsg_stft_args* args, 
     }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(user, &cap);
-    const int n_s = count < kPoolStreams ? count : kPoolStreams;
-    // fork: the pool streams start behind everything already enqueued on the caller's stream
+    // launches of the one-workgroup-per-CU kernels (2048 / 4096 "B") fill the GPU by themselves: two streams are enough to hide
+    // the ramp-up and drain (measured at C3, round 2), four make them queue behind each other
+    int nc0 = args[0].channels;
+    if (args[0].mix_mode == JSG_MIX_LEFT || args[0].mix_mode == JSG_MIX_RIGHT || args[0].mix_mode == JSG_MIX_PER_CHANNEL) nc0 = 1;
+    const int want_s = wants_plan_b(plan->n, &args[0], nc0, cu_count_of_device(dev)) ? 2 : kPoolStreams;
+    const int n_s = count < want_s ? count : want_s;     // working streams: sv[0] = the caller's, sv[1..] = the library's
+    // fork: the library's streams start behind everything already enqueued on the caller's stream
     err = hipEventRecord(p.fork, user);
-    for (int i = 0; i < n_s && err == hipSuccess; ++i) err = hipStreamWaitEvent(p.s[i], p.fork, 0);
+    for (int i = 0; i + 1 < n_s && err == hipSuccess; ++i) err = hipStreamWaitEvent(p.s[i], p.fork, 0);
     if (err != hipSuccess) return jsg_fail_hip(err, "jsg_stft_db_launch_batches: fork");
-    void* sv[kPoolStreams];
-    for (int i = 0; i < kPoolStreams; ++i) sv[i] = p.s[i];
+    void* sv[kPoolStreams] = {user, p.s[0], p.s[1], p.s[2]};
+    // (the default stream cannot be named by a null handle in a round-robin table: launch_many treats NULL as "default stream" too)
     const int rc = jsg_stft_db_launch_many_threads(plan, args, count, sv, n_s, cap == hipStreamCaptureStatusActive ? 1 : kPoolThreads);
     // join (also after a failed launch: what was enqueued must still be ordered before the caller's later work)
-    for (int i = 0; i < n_s && err == hipSuccess; ++i) {
+    for (int i = 0; i + 1 < n_s && err == hipSuccess; ++i) {
         err = hipEventRecord(p.join[i], p.s[i]);
         if (err == hipSuccess) err = hipStreamWaitEvent(user, p.join[i], 0);
     }

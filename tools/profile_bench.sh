@@ -22,7 +22,10 @@ echo "$CMD" > $OUT/command.txt
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1 || echo "stats pass failed"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $PMC_CMD > $OUT/fetch.log 2>&1 || echo "fetch pass failed"
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $PMC_CMD > $OUT/write.log 2>&1 || echo "write pass failed"
-timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY --output-format csv -d $OUT/sq -- $PMC_CMD > $OUT/sq.log 2>&1 || echo "sq pass failed"
+# SQ counters: three passes of at most eight (the block has eight slots), never combined with tracing
+timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/sq -- $PMC_CMD > $OUT/sq.log 2>&1 || echo "sq pass failed"
+timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INST_LEVEL_VMEM --output-format csv -d $OUT/sq2 -- $PMC_CMD > $OUT/sq2.log 2>&1 || echo "sq2 pass failed"
+timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INST_LEVEL_LDS SQ_IFETCH SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq3 -- $PMC_CMD > $OUT/sq3.log 2>&1 || echo "sq3 pass failed"
 grep -h '"metric"' $OUT/stats.log | head -1 > $OUT/bench_lines.jsonl
 python3 $GRAFT_REPO_ROOT/tools/profile_summarize.py $OUT $TAG $CFG
 # the raw per-dispatch files are large (tens of MB per configuration; gpurun copies back at most 64 MiB): keep the summaries

@@ -64,5 +64,24 @@ if fetch and write:
     res["traffic_over_algorithmic"] = res["hbm_bytes_per_launch"] / res["algorithmic_bytes_per_launch"]
     if "avg_us" in res:
         res["frac_of_8p0_from_trace_avg"] = res["algorithmic_bytes_per_launch"] / (res["avg_us"] * 1e-6) / 8e12
+# derived: instructions per FFT and how busy the vector and LDS pipes were (SQ counters are per dispatch means; SQ_WAVE_CYCLES and
+# SQ_ACTIVE_INST_* count quad-cycles summed over the waves, SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES LDS-array / CU cycles)
+c = bench.CONFIGS[cfg]
+ffts = c["frames"] * c["channels"]
+for kname, d in res["counters_mean_per_dispatch"].items():
+    if "stft_db_kernel" not in kname or "SQ_WAVE_CYCLES" not in d:
+        continue
+    w = d.get("SQ_WAVES", 0.0)
+    der = {"ffts_per_dispatch": ffts, "waves": w,
+           "valu_instructions_per_fft": d.get("SQ_INSTS_VALU", 0.0) / ffts, "lds_instructions_per_fft": d.get("SQ_INSTS_LDS", 0.0) / ffts,
+           "vmem_instructions_per_fft": d.get("SQ_INSTS_VMEM", 0.0) / ffts,
+           "wave_lifetime_cycles": 4.0 * d["SQ_WAVE_CYCLES"] / max(w, 1.0),
+           "share_of_wave_cycles": {k: d[v] / d["SQ_WAVE_CYCLES"] for k, v in (("issuing_valu", "SQ_ACTIVE_INST_VALU"), ("issuing_any", "SQ_ACTIVE_INST_ANY"),
+                                                                              ("waiting_to_issue", "SQ_WAIT_INST_ANY"), ("parked_on_waitcnt_or_barrier", "SQ_WAIT_ANY"),
+                                                                              ("waiting_to_issue_lds", "SQ_WAIT_INST_LDS")) if v in d},
+           "lds_bank_conflict_share_of_lds_cycles": (d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]) if d.get("SQ_LDS_IDX_ACTIVE") else None,
+           "lds_array_cycles_per_fft": d.get("SQ_LDS_IDX_ACTIVE", 0.0) / ffts,
+           "note": "issuing_valu x (waves per SIMD: 4 at C2, 2 at C3 / C5) = share of the time a SIMD's vector pipe is issuing"}
+    res.setdefault("derived", {})[kname] = der
 json.dump(res, open(os.path.join(dst, f"{tag}_{cfg}_hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
