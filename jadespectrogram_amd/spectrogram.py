@@ -273,6 +273,19 @@ def stft_db(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: int
     check(lib().jsg_stft_db_launch(plan._p, C.byref(a), C.c_void_p(stream)))
 
 
+def stft_db_batches(plan: Plan, batches, hop: int, n_frames: int, *, stream: int | None = None, **kw):
+    """jsg_stft_db_launch_batches: `batches` = [(d_in, d_out), ...] independent launches of the same geometry, stream-ordered with
+    respect to `stream` like one launch but overlapped on the library's own working streams (include/jsg.h)."""
+    import torch
+    arr = (capi.StftArgs * len(batches))()
+    for i, (d_in, d_out) in enumerate(batches):
+        a = _stft_args(plan, d_in, hop, n_frames, d_out, **kw)
+        C.memmove(C.byref(arr, i * C.sizeof(capi.StftArgs)), C.byref(a), C.sizeof(capi.StftArgs))
+    if stream is None:
+        stream = torch.cuda.current_stream(batches[0][0].device).cuda_stream
+    check(lib().jsg_stft_db_launch_batches(plan._p, arr, len(batches), C.c_void_p(stream)))
+
+
 def stft_kernel_name(plan: Plan, d_in, hop: int, n_frames: int, d_out, **kw) -> str:
     """The kernel configuration jsg_stft_db_launch picks for this launch ("Cfg1024", "Cfg2048B", ...)."""
     a = _stft_args(plan, d_in, hop, n_frames, d_out, **kw)

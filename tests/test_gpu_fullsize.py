@@ -430,3 +430,50 @@ def test_baseline_config_accuracy_contract(jsg, oracle, torch_cuda, cfg, kernel,
     assert rep["colour_index_flips_end_to_end"] <= -(-rep["pixels_checked"] // 50000), rep
     assert rep["fused_image_pixels_differing_from_two_kernel_image"] == 0, rep
     assert rep["max_abs_db_err"] < 0.1, rep
+
+
+@pytest.mark.parametrize("n,C,F,count", [(1024, 1, 1000, 13), (2048, 8, 4096, 3), (4096, 2, 1875, 2)])
+def test_launch_batches_is_stream_ordered_and_equals_in_order_launches(jsg, oracle, torch_cuda, n, C, F, count):
+    """jsg_stft_db_launch_batches (the library's own launch pool: the caller's stream + three of the library's, two issuing
+    threads): the batches' columns equal those of one launch after the other, work enqueued on the caller's stream BEFORE the call is
+    seen by the batches (the inputs are produced on that stream) and work enqueued AFTER it sees their results, without any host
+    synchronisation in between; the call can also be captured into a hipGraph and replayed."""
+    torch = torch_cuda
+    hop = 512
+    fb = n // hop
+    win = oracle.window(oracle.WIN_HANN, n)
+    plan = jsg.Plan(n, win)
+    H, pitch = n // 2 + 1, (n // 2 + 1 + 31) // 32 * 32
+    src = [_stream(torch, C, F * hop + n - hop, seed=100 + i) for i in range(count)]
+    ref = [torch.empty((F, pitch), device="cuda") for _ in range(count)]
+    for i in range(count):
+        jsg.stft_db(plan, src[i], hop, F, ref[i], feedblocks=fb)
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    d_in = [torch.zeros_like(x) for x in src]
+    d_out = [torch.full((F, pitch), -7.0, device="cuda") for _ in range(count)]
+    gathered = torch.empty((count, F, H), device="cuda")
+    with torch.cuda.stream(st):
+        for i in range(count):
+            d_in[i].copy_(src[i], non_blocking=True)             # producers on the caller's stream, just before the call
+        jsg.stft_db_batches(plan, list(zip(d_in, d_out)), hop, F, stream=st.cuda_stream, feedblocks=fb)
+        for i in range(count):
+            gathered[i].copy_(d_out[i][:, :H], non_blocking=True)   # consumers on the caller's stream, right behind it
+    torch.cuda.synchronize()
+    for i in range(count):
+        assert torch.equal(gathered[i], ref[i][:, :H]), i
+    # captured into a graph (the launches become parallel branches) and replayed on fresh outputs
+    for o in d_out:
+        o.fill_(-7.0)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(g, stream=st):
+            jsg.stft_db_batches(plan, list(zip(d_in, d_out)), hop, F, stream=st.cuda_stream, feedblocks=fb)
+    torch.cuda.synchronize()
+    for o in d_out:
+        o.fill_(-7.0)
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    for i in range(count):
+        assert torch.equal(d_out[i][:, :H], ref[i][:, :H]), ("graph", i)
