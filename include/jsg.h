@@ -139,7 +139,7 @@ typedef struct jsg_stft_args {
                                 workgroup of 16 / 8 columns per CU; faster when it can fill the GPU) for launches that fill their
                                 rounds of <CU count> workgroups to at least 87 % (e.g. 3584..4096 columns of 2048 points or
                                 1784..2048 of 4096 points on 256 CUs, or any launch of 7 rounds and more) AND, at 2048 points, mix
-                                >= 3 channels per column (at 4096 points "B" is ahead at every channel count); the small-workgroup
+                                >= 2 channels per column (at 4096 points "B" is ahead at every channel count); the small-workgroup
                                 kernel otherwise.  1: always the small-workgroup kernel, 2: always "B".  The two round differently in
                                 the last bits (both inside the parity bound): callers that cut one stream into launches of
                                 very different sizes and need bit-identical columns pin one of them (the engine pins 1).

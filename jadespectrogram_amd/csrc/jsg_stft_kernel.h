@@ -289,7 +289,9 @@ using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, JSG_X_WPB2048, 1, JSG_X_W
 // for anything smaller the 4-frame workgroups of the three-stage plan use more CUs (tools/abbench --cfg x2048 / mid).
 // The launcher picks by channel count and by how well the launch fills its rounds (stft_launch_impl).
 using Cfg2048B = Cfg<2048, 32, 32, 1, 32, 34, 0, 0, 0, 8, 1, 1>;
-constexpr int k2048B_min_channels = 3;   // channels mixed into one column from which the two-stage plan is the faster one
+constexpr int k2048B_min_channels = 2;   // channels mixed into one column from which the two-stage plan is the faster one (round 3, ILP-first
+                                         // scheduler, 32 768 FFTs per launch: stereo 42.9-52.8 vs 48.1-55.9 us, 4 ch 41.3-49.1 vs 45.1-52.0, 8 ch
+                                         // 39.6-46.5 vs 44.8-50.6; mono level: 51.2-62.7 vs 52.1-61.2)
 constexpr int k4096B_min_channels = 1;   // ... the one-wavefront-per-frame 4096-point plan is ahead at every channel count once the rounds are
                                          // full (round 3, 16 384 FFTs, inputs and rings rotating over 1 GB: mono 66.5 vs 73.4 us, stereo 56.7 vs 60.8,
                                          // 4 ch 51.6 vs 57.6, 8 ch 50.3 vs 54.7); launches that do not fill their rounds keep the two-wave plan

@@ -251,9 +251,9 @@ def test_persistent_loop_of_every_plan(jsg, oracle, torch_cuda, n, F, C):
     d_a = torch.empty((F, pitch), device="cuda")
     d_b = torch.empty((F, pitch), device="cuda")
     fb = n // hop
-    # 4096 points (any channel count) and >= 3 channels at 2048 points: the automatic kernel choice looks at how well a launch
+    # 4096 points (any channel count) and >= 2 channels at 2048 points: the automatic kernel choice looks at how well a launch
     # fills its rounds, which differs between the whole and the halves -- bit-identical sub-launches are what plan_select is for
-    sel = 2 if (n == 4096 or (C >= 3 and n == 2048)) else 0
+    sel = 2 if (n == 4096 or (C >= 2 and n == 2048)) else 0
     jsg.stft_db(plan, d_in, hop, F, d_a, feedblocks=fb, plan_select=sel)
     half = F // 2 + 3
     jsg.stft_db(plan, d_in, hop, half, d_b, feedblocks=fb, plan_select=sel)

@@ -327,7 +327,7 @@ def test_ragged_frame_counts(jsg, oracle, torch_cuda, n, frames):
 @pytest.mark.parametrize("n,channels", [(2048, 4), (512, 2), (512, 1), (4096, 5)])
 @pytest.mark.parametrize("frames", [1, 2, 5, 16, 33])
 def test_ragged_frame_counts_two_frames_per_wavefront(jsg, oracle, torch_cuda, n, channels, frames):
-    """The 32-lane plans (512 points; 2048 points with >= 3 channels) put two frames into one wavefront and trade
+    """The 32-lane plans (512 points; 2048 points with >= 2 channels) put two frames into one wavefront and trade
     register halves before the column store: odd frame counts (the upper frame of the last wavefront is a duplicate of
     the lower one) and a ring whose wrap falls between the two frames of a wavefront."""
     torch = torch_cuda
@@ -355,7 +355,7 @@ def test_ragged_frame_counts_two_frames_per_wavefront(jsg, oracle, torch_cuda, n
 @pytest.mark.parametrize("n", [2048, 4096])
 def test_2048_and_4096_point_plans_agree(jsg, oracle, torch_cuda, n):
     """2048 and 4096 points have two kernels each: the small-workgroup plan and the "B" plan (two-stage / one wavefront per
-    frame with factorised tables; picked automatically for launches that mix >= 3 channels per column and fill the GPU).
+    frame with factorised tables; picked automatically for launches that fill the GPU -- at 2048 points from two channels per column on).
     Linear power of both, for every channel count, against the float64 DFT; and the same stream through both (channels
     duplicated so that the mixes are equal) stays within the float32 bound of one another."""
     torch = torch_cuda
