@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define JSG_ABI_VERSION 2
+#define JSG_ABI_VERSION 3
 
 typedef enum jsg_status {
     JSG_OK = 0,
