@@ -274,7 +274,10 @@ struct Cfg {
 #define JSG_X_WPS2048 3
 #endif
 using Cfg512 = Cfg<512, 8, 8, 4, 32, 36, 4, 33, 1, 8, 1, 2>;   // (a 80-VGPR budget = 3 workgroups per CU measured no faster)
-using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, JSG_X_WPB1024, 1, 2, JSG_X_FPW1024, JSG_X_ABL>;
+#ifndef JSG_X_WPS1024     // six waves per SIMD = three 8-wave workgroups per CU (their LDS allows exactly three): <= 80 VGPRs for EVERY instantiation.
+#define JSG_X_WPS1024 6   // Left at 2 the ILP-first scheduler takes 88 for the mixing instantiations (two workgroups per CU): stereo -2..-4 % with the cap
+#endif
+using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, JSG_X_WPB1024, 1, JSG_X_WPS1024, JSG_X_FPW1024, JSG_X_ABL>;
 #ifndef JSG_X_TWF2048      // factorised stage-2 / post tables (Cfg::TWF): 11.3 instead of 21.2 KB of tables, so that THREE 4-wave
 #define JSG_X_TWF2048 1    // workgroups fit a CU (12 waves instead of 8): stereo launches -9..-13 %, mono -1..-5 %
 #endif

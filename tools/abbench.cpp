@@ -99,6 +99,9 @@ static const Config kConfigs[] = {
     {"c4", 1024, 512, 8, 4096, JSG_MIX_PER_CHANNEL, false},// configs[3] shard: 8 ch per GPU, per-channel columns
     {"c5", 4096, 512, 2, 1875, JSG_MIX_ABSMEAN, true},     // configs[4]: stereo, 87.5 % overlap, 10 s ring -> ARGB
     {"big", 1024, 512, 1, 65536, JSG_MIX_ABSMEAN, false},  // asymptotic rate of the 1024-point plan
+    {"s1024", 1024, 512, 2, 4096, JSG_MIX_ABSMEAN, false},  // the plugin's stereo bus at 1024 points (mixed kernel instantiation)
+    {"s1024", 1024, 512, 2, 32768, JSG_MIX_ABSMEAN, false},
+    {"s1024", 1024, 512, 8, 8192, JSG_MIX_ABSMEAN, false},
     {"c3big", 2048, 512, 8, 16384, JSG_MIX_ABSMEAN, false},
     {"n512", 512, 256, 1, 131072, JSG_MIX_ABSMEAN, false},   // single plans (counter passes: tools/pmc_ab.sh r02_n512 n512 ...)
     {"n8192", 8192, 4096, 1, 8192, JSG_MIX_ABSMEAN, false},
