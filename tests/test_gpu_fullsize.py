@@ -477,3 +477,32 @@ def test_launch_batches_is_stream_ordered_and_equals_in_order_launches(jsg, orac
     torch.cuda.synchronize()
     for i in range(count):
         assert torch.equal(d_out[i][:, :H], ref[i][:, :H]), ("graph", i)
+
+
+def test_image_launch_error_paths_return_codes(jsg, oracle, torch_cuda):
+    """nothing fatal crosses the C boundary.  ring_width = 0 in both halves of the image arguments used to reach a
+    modulo by zero (SIGFPE in the host process); a launch that needs the index scratch says so instead of dereferencing NULL."""
+    import ctypes as C
+    torch = torch_cuda
+    from jadespectrogram_amd.spectrogram import _stft_image_args
+    cap = jsg.capi
+    lib = cap.lib()
+    n, hop, F = 2048, 512, 64
+    plan = jsg.Plan(n, oracle.window(oracle.WIN_HANN, n))
+    d_in = _stream(torch, 2, (F - 1) * hop + n, seed=3)
+    d_lut = torch.from_numpy(jsg.colormap_lut(256, cap.CM_JADE)).cuda()
+    img = torch.zeros((n // 2 + 1, F), dtype=torch.int32, device="cuda")
+    # 2048 points: two kernels -> the scratch is required
+    assert jsg.stft_image_needs_scratch(plan, d_in, hop, F, d_lut, -50.0, 50.0, img, None, feedblocks=4)
+    with pytest.raises(jsg.JsgError) as ei:
+        jsg.stft_image(plan, d_in, hop, F, d_lut, -50.0, 50.0, img, None, feedblocks=4)
+    assert ei.value.code == cap.JSG_ERR_INVALID and "index_scratch" in str(ei.value)
+    a = _stft_image_args(plan, d_in, hop, F, d_lut, -50.0, 50.0, img, None, feedblocks=4)
+    a.stft.ring_width = 0
+    a.colour.ring_width = 0
+    assert lib.jsg_stft_image_launch(plan._p, C.byref(a), None) == cap.JSG_ERR_INVALID
+    a = _stft_image_args(plan, d_in, hop, F, d_lut, -50.0, 50.0, img, None, feedblocks=4)
+    a.colour.col_first = -1
+    assert lib.jsg_stft_image_launch(plan._p, C.byref(a), None) == cap.JSG_ERR_INVALID
+    torch.cuda.synchronize()
+    assert not img.any()      # nothing was launched

@@ -75,6 +75,20 @@ def test_bad_arguments_are_rejected(jsg):
     assert lib.jsg_window_build(9, 1024, np.zeros(1024, np.float32).ctypes.data) == jsg.capi.JSG_ERR_INVALID
     assert lib.jsg_colormap_build(256, 7, np.zeros(256, np.int32).ctypes.data) == jsg.capi.JSG_ERR_INVALID
     assert lib.jsg_feed_samples(50.0, 0) == jsg.capi.JSG_ERR_INVALID
+    # the round-3 entry points refuse null / malformed arguments with a code (nothing fatal crosses the C boundary, no GPU needed)
+    import ctypes as C
+    cap = jsg.capi
+    a = cap.StftArgs()
+    buf = C.create_string_buffer(32)
+    assert lib.jsg_stft_kernel_name(None, C.byref(a), buf, 32) == cap.JSG_ERR_INVALID
+    assert lib.jsg_stft_db_launch_batches(None, C.byref(a), 2, None) == cap.JSG_ERR_INVALID
+    assert lib.jsg_stft_db_launch_batches(None, None, 0, None) == cap.JSG_ERR_INVALID      # a plan is required even for an empty list
+    assert lib.jsg_stft_db_launch_many_threads(None, C.byref(a), 1, None, 0, 2) == cap.JSG_ERR_INVALID
+    ia = cap.StftImageArgs()
+    assert lib.jsg_stft_image_needs_scratch(None, C.byref(ia)) == cap.JSG_ERR_INVALID
+    assert lib.jsg_stft_image_launch(None, C.byref(ia), None) == cap.JSG_ERR_INVALID
+    msg = lib.jsg_last_error(None)
+    assert msg and b"null" in msg
 
 
 def test_no_cpu_fallback(jsg):
