@@ -94,6 +94,8 @@ def test_reblocker_resize_race_under_sanitizers(flags):
     exe = _cxx(["-O1"] + flags + [os.path.join(ROOT, "tests", "cpp", "reblocker_race_test.cpp"), "-lpthread"],
                os.path.join(d, "jsg_rb_race_" + flags[0].split("=")[1].split(",")[0]))
     r = subprocess.run([exe], capture_output=True, text=True)
+    if "unexpected memory mapping" in r.stderr:    # the sanitizer runtime cannot start under this kernel's address-space layout
+        pytest.skip("ThreadSanitizer cannot run on this host (unexpected memory mapping: ASLR entropy too high for its shadow)")
     assert r.returncode == 0, r.stdout + r.stderr
     assert "bad 0" in r.stdout and "WARNING" not in r.stderr
     exe2 = _cxx(["-O1"] + flags + [os.path.join(ROOT, "tests", "cpp", "reblocker_test.cpp"), "-lpthread"],
