@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define JSG_ABI_VERSION 3
+#define JSG_ABI_VERSION 3   /* 3: + kernel-name query, launch pool, image scratch query, sharded set (round 3) */
 
 typedef enum jsg_status {
     JSG_OK = 0,
@@ -242,6 +242,14 @@ int jsg_create(jsg_engine** out, int channels);
  * single-process host that drives several GPUs uses, one engine per device ("Several GPUs"). */
 int jsg_create_on_device(jsg_engine** out, int channels, int device);
 int jsg_get_device(const jsg_engine* e);
+/* One engine per entry of `devices` (entries may repeat), the `channels` channels of one stream dealt out in contiguous runs
+ * whose sizes differ by at most one: entry i owns [first_channel[i], first_channel[i] + channel_count[i]) and gets no engine
+ * (out[i] = NULL) when that run is empty.  The engines share nothing -- the path shards by independent channels, there is no
+ * collective (a cross-GPU AbsMean is the one exchange: INTEGRATION.md C).  Configure every engine with the usual setters.
+ * jsg_process_block_sharded hands every engine its run of the planar pointers (enqueue only); jsg_destroy_sharded frees the set. */
+int jsg_create_sharded(jsg_engine** out, int* first_channel, int* channel_count, const int* devices, int n_devices, int channels);
+int jsg_process_block_sharded(jsg_engine* const* engines, const int* first_channel, int n_devices, const float* const* planar);
+int jsg_destroy_sharded(jsg_engine** engines, int n_devices);
 int jsg_destroy(jsg_engine* e);
 const char* jsg_last_error(const jsg_engine* e);   /* e may be NULL: last error of the calling thread */
 

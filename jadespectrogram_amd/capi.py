@@ -80,6 +80,9 @@ SIGNATURES = {
     "jsg_create": (C.c_int, [C.POINTER(_P), C.c_int]),
     "jsg_create_on_device": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int]),
     "jsg_get_device": (C.c_int, [_P]),
+    "jsg_create_sharded": (C.c_int, [C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int]),
+    "jsg_process_block_sharded": (C.c_int, [C.POINTER(_P), C.POINTER(C.c_int), C.c_int, C.POINTER(_P)]),
+    "jsg_destroy_sharded": (C.c_int, [C.POINTER(_P), C.c_int]),
     "jsg_destroy": (C.c_int, [_P]),
     "jsg_last_error": (C.c_char_p, [_P]),
     "jsg_set_samplerate": (C.c_int, [_P, C.c_float]),

@@ -405,6 +405,52 @@ int jsg_create_on_device(jsg_engine** out, int channels, int device) {
 
 int jsg_get_device(const jsg_engine* e) { return e ? e->device : JSG_ERR_INVALID; }
 
+// Several GPUs from one host process (SURVEY 8b "jsg_create_sharded(devices[], n)", 8e): one engine per entry of `devices`, the
+// `channels` channels of one stream dealt out in contiguous runs whose sizes differ by at most one (BASELINE configs[3]: 64
+// channels -> 8 per GPU).  Entry i gets channels [first_channel[i], first_channel[i] + channel_count[i]); an entry that gets no
+// channel gets no engine (out[i] = NULL).  The engines share nothing: outputs stay on their device, there is no collective.
+int jsg_create_sharded(jsg_engine** out, int* first_channel, int* channel_count, const int* devices, int n_devices, int channels) {
+    if (!out || !first_channel || !channel_count || !devices || n_devices <= 0 || channels <= 0)
+        return jsg_fail(JSG_ERR_INVALID, "jsg_create_sharded: bad argument");
+    for (int i = 0; i < n_devices; ++i) out[i] = nullptr;
+    const int base = channels / n_devices, extra = channels % n_devices;
+    for (int i = 0; i < n_devices; ++i) {
+        first_channel[i] = i * base + (i < extra ? i : extra);
+        channel_count[i] = base + (i < extra ? 1 : 0);
+        if (channel_count[i] == 0) continue;
+        const int rc = devices[i] < 0 ? jsg_fail(JSG_ERR_INVALID, "jsg_create_sharded: negative device index")
+                                      : create_on(&out[i], channel_count[i], devices[i]);
+        if (rc != JSG_OK) {
+            const std::string keep = tls_error();
+            for (int k = 0; k < i; ++k) { (void)jsg_destroy(out[k]); out[k] = nullptr; }
+            tls_error() = keep;
+            return rc;
+        }
+    }
+    return JSG_OK;
+}
+
+// processSynchronBlock for the sharded set: every engine takes its own run of the planar channel pointers.  Enqueue only, like
+// jsg_process_block; the first failing engine's code is returned (its text: jsg_last_error(engine)).
+int jsg_process_block_sharded(jsg_engine* const* engines, const int* first_channel, int n_devices, const float* const* planar) {
+    if (!engines || !first_channel || n_devices <= 0 || !planar) return jsg_fail(JSG_ERR_INVALID, "jsg_process_block_sharded: bad argument");
+    for (int i = 0; i < n_devices; ++i) {
+        if (!engines[i]) continue;
+        const int rc = jsg_process_block(engines[i], planar + first_channel[i]);
+        if (rc != JSG_OK) return rc;
+    }
+    return JSG_OK;
+}
+
+int jsg_destroy_sharded(jsg_engine** engines, int n_devices) {
+    if (!engines) return JSG_OK;
+    for (int i = 0; i < n_devices; ++i) {
+        (void)jsg_destroy(engines[i]);
+        engines[i] = nullptr;
+    }
+    return JSG_OK;
+}
+
 int jsg_destroy(jsg_engine* e) {
     if (!e) return JSG_OK;
     (void)hipSetDevice(e->device);

@@ -87,8 +87,32 @@ int main(int argc, char** argv) {
         diff += std::memcmp(got.data(), ref.data() + size_t(first[size_t(s)]) * W * H, got.size() * sizeof(float)) != 0;
         CK(jsg_destroy(eng[size_t(s)]));
     }
+    // the same through the convenience entry points (jsg_create_sharded): one call creates the set, one call per block feeds it
+    std::vector<jsg_engine*> set(ns, static_cast<jsg_engine*>(nullptr));
+    std::vector<int> sfirst(ns, 0), scount(ns, 0), devs(ns, 0);
+    for (int s = 0; s < shards; ++s) devs[size_t(s)] = s % ndev;
+    CK(jsg_create_sharded(set.data(), sfirst.data(), scount.data(), devs.data(), shards, C));
+    size_t api_diff = 0;
+    for (int s = 0; s < shards; ++s) {
+        api_diff += sfirst[size_t(s)] != first[size_t(s)] || scount[size_t(s)] != count[size_t(s)];
+        if (set[size_t(s)]) configure(set[size_t(s)]);
+    }
+    std::vector<const float*> all(static_cast<size_t>(C));
+    for (int b = 0; b < blocks; ++b) {
+        for (int c = 0; c < C; ++c) all[size_t(c)] = x.data() + size_t(c) * blocks * N + size_t(b) * N;
+        CK(jsg_process_block_sharded(set.data(), sfirst.data(), shards, all.data()));
+    }
+    for (int s = 0; s < shards; ++s) {
+        if (!set[size_t(s)]) continue;
+        std::vector<float> got(size_t(scount[size_t(s)]) * W * H);
+        int pos = -1;
+        CK(jsg_peek_mem(set[size_t(s)], got.data(), scount[size_t(s)] * W, &pos));
+        api_diff += pos != pos_ref;
+        api_diff += std::memcmp(got.data(), ref.data() + size_t(sfirst[size_t(s)]) * W * H, got.size() * sizeof(float)) != 0;
+    }
+    CK(jsg_destroy_sharded(set.data(), shards));
     CK(jsg_destroy(whole));
-    std::printf("{\"devices\": %d, \"shards\": %d, \"channels\": %d, \"columns\": %d, \"shards_differing\": %zu, \"pos_mismatch\": %d}\n", ndev,
-                shards, C, 2 * blocks, diff, pos_bad);
-    return diff == 0 && pos_bad == 0 ? 0 : 1;
+    std::printf("{\"devices\": %d, \"shards\": %d, \"channels\": %d, \"columns\": %d, \"shards_differing\": %zu, \"pos_mismatch\": %d, \"sharded_api_differing\": %zu}\n", ndev,
+                shards, C, 2 * blocks, diff, pos_bad, api_diff);
+    return diff == 0 && pos_bad == 0 && api_diff == 0 ? 0 : 1;
 }

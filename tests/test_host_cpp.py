@@ -165,6 +165,7 @@ def test_several_engines_from_one_host_process(jsg, shards):
     assert r.returncode == 0, r.stdout + r.stderr
     info = json.loads(r.stdout.strip().splitlines()[-1])
     assert info["shards"] == shards and info["shards_differing"] == 0 and info["pos_mismatch"] == 0 and info["columns"] == 24
+    assert info["sharded_api_differing"] == 0      # jsg_create_sharded / jsg_process_block_sharded: the same shards, the same bits
 
 
 def _build_rccl_example(jsg):
