@@ -99,13 +99,13 @@ def _cpu_model() -> str:
 
 
 def kernel_source_sha() -> str:
-    """Hash of the sources the kernels are built from (csrc/ + include/jsg.h + the build flags in _build.py): a profile under
-    profiles/ describes this build exactly when it carries the same hash, whatever was committed in between."""
+    """Hash of the sources the kernels and their launcher are built from (the three .hip units, the kernel header and the build
+    flags in _build.py): a profile under profiles/ describes this build exactly when it carries the same hash, whatever else was
+    committed in between (host-side engine code, headers' comments, tests, documents)."""
     import hashlib
     h = hashlib.sha256()
     base = os.path.join(ROOT, "jadespectrogram_amd")
-    files = sorted(os.path.join(base, "csrc", f) for f in os.listdir(os.path.join(base, "csrc"))) + [os.path.join(base, "_build.py"),
-                                                                                                       os.path.join(ROOT, "include", "jsg.h")]
+    files = [os.path.join(base, "csrc", f) for f in ("jsg_stft_kernel.h", "jsg_stft_a.hip", "jsg_stft_b.hip", "jsg_kernels.hip")] + [os.path.join(base, "_build.py")]
     for f in files:
         h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
