@@ -1,21 +1,13 @@
-// Hand-written HIP kernels for gfx950 (MI355X, CDNA4): the STFT -> dB hot path and the colour loop.
+// libjsg.so, device side: the colour loop kernel, the plans (lane tables), the launcher and the stateless C-ABI entry points.
 //
-//   stft_db_kernel   L lanes transform one real frame (64 = one wavefront per frame; 32: two frames per wave at
-//                    N = 512 and in the two-stage N = 2048 plan; 128 / 256: two / four wavefronts per frame at
-//                    N = 4096 / 8192):
-//                    lane tables (window, twiddles) staged once per workgroup into LDS, issued ahead of the frame
-//                    loads so that the one workgroup barrier completes while those are in flight; coalesced 8-byte
-//                    loads of the frame straight from the audio stream in HBM, software-prefetched (the 50..87.5 %
-//                    overlap of neighbouring frames is served by L1/L2: neighbouring frames sit in one workgroup);
-//                    window multiply; N/2-point complex FFT as three register-resident radix stages with two
-//                    bank-conflict-free LDS exchanges (wave-private and barrier-free for L <= 64), or two radix-32
-//                    stages with one exchange (Cfg2048B); paired real-split post pass (X[k] and X[N/2-k] from one
-//                    butterfly, both |X|^2 formed side by side in packed math); channel mix in registers (pair
-//                    accumulators); 10*log10 on the hardware log unit; non-temporal 256-byte coalesced ring stores.
-//                    No MFMA: the path is bandwidth / latency / VALU-issue bound, not a contraction.
+//   stft_db_kernel   (jsg_stft_kernel.h; instantiated in jsg_stft_a.hip for 512 / 1024 / 2048 / 8192 points and in jsg_stft_b.hip for
+//                    4096 points -- two units because the two groups want different machine schedulers) framing + window + real FFT +
+//                    |X|^2 + channel mix + dB + ring store, or palette indices, or the ARGB rows of its own eight columns.
 //                    Replaces Spectrogram.cpp:50-119 + :137-145 + spectrum::power (call site :144) of the reference.
-//   colormap_kernel  dB ring columns -> ARGB image rows (transpose through LDS so both sides are coalesced),
+//   colormap_kernel  (here) dB ring columns -> ARGB image rows (transpose through LDS so both sides are coalesced),
 //                    CColorPalette::getRGBColor inlined.  Replaces Spectrogram.cpp:632-648 / :673-680 / :693-700.
+//   launcher         stft_launch_impl: which kernel a launch takes (wants_plan_b: launch fill, channel count, CU count of the device),
+//                    grid and loop counts; jsg_stft_db_launch_batches: the library's launch pool (caller's stream + three).
 //
 // The index algebra, the twiddle tables and the LDS layouts are modelled and checked in tools/fft_model.py.
 #include "jsg_stft_kernel.h"
