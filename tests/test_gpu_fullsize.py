@@ -479,6 +479,33 @@ def test_launch_batches_is_stream_ordered_and_equals_in_order_launches(jsg, orac
         assert torch.equal(d_out[i][:, :H], ref[i][:, :H]), ("graph", i)
 
 
+@pytest.mark.parametrize("n,C,F,Wimg,x_first", [(4096, 2, 1875, 1888, 0), (4096, 2, 1875, 1888, 8), (4096, 2, 1873, 1888, 12), (4096, 3, 2048, 2048, 1024),
+                                                 (1024, 1, 1001, 1004, 0), (1024, 2, 512, 512, 256), (1024, 1, 999, 1000, 3), (4096, 2, 1875, 1875, 0)])
+def test_one_kernel_image_alignments_wraps_and_ragged_widths(jsg, oracle, torch_cuda, n, C, F, Wimg, x_first):
+    """The one-kernel display path at aligned and odd x_first, with and without a wrap in x, ragged column counts (the last
+    workgroup partly dead), image widths that are and are not the launch width: always the two-kernel image bit for bit, and
+    the rest of the image untouched.  (A 16-byte store form for aligned launches was built in round 3 and measured slower --
+    DESIGN.md section 6 -- these cases stay as its geometry coverage.)"""
+    torch = torch_cuda
+    hop = 512
+    fb = n // hop
+    plan = jsg.Plan(n, oracle.window(oracle.WIN_HANN, n))
+    d_in = _stream(torch, C, (F - 1) * hop + n, seed=n + F)
+    H = n // 2 + 1
+    d_lut = torch.from_numpy(jsg.colormap_lut(256, jsg.capi.CM_JADE)).cuda()
+    d_db = torch.empty((F, (H + 31) // 32 * 32), device="cuda")
+    sel = 2 if n == 4096 else 0
+    two = torch.full((H, Wimg), 0x12345678, dtype=torch.int32, device="cuda")
+    one = torch.full((H, Wimg), 0x12345678, dtype=torch.int32, device="cuda")
+    jsg.stft_db(plan, d_in, hop, F, d_db, feedblocks=fb, plan_select=sel)
+    jsg.colormap(d_db, d_lut, -60.0, 40.0, d_argb=two, x_first=x_first, n_cols=F, height=H)
+    assert not jsg.stft_image_needs_scratch(plan, d_in, hop, F, d_lut, -60.0, 40.0, one, None, feedblocks=fb, ring_width=F, x_first=x_first, plan_select=sel)
+    jsg.stft_image(plan, d_in, hop, F, d_lut, -60.0, 40.0, one, None, feedblocks=fb, ring_width=F, x_first=x_first, plan_select=sel)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two)
+    assert int((one == 0x12345678).sum()) == H * (Wimg - F)        # columns the launch does not own keep their pixels
+
+
 def test_image_launch_error_paths_return_codes(jsg, oracle, torch_cuda):
     """nothing fatal crosses the C boundary.  ring_width = 0 in both halves of the image arguments used to reach a
     modulo by zero (SIGFPE in the host process); a launch that needs the index scratch says so instead of dereferencing NULL."""
