@@ -63,3 +63,26 @@ def test_other_configs_emit_a_line(cfg, unit):
     assert j["unit"] == unit and j["value"] > 0 and j["roofline"]["algorithmic_bytes_per_launch"] > 0
     assert j["parity"]["max_rel_power_err_bins_within_20dB_of_peak"] < 1e-5
     assert j["parity"]["colour_index_flips_end_to_end"] <= max(4, j["parity"]["pixels_checked"] // 500)
+
+
+@pytest.mark.gpu
+def test_default_config_line_carries_roofline_boundary_and_default_environment():
+    """The driver's line (configs[1]) with few launches per step: the objects the contract asks for are there and consistent --
+    roofline (fraction, source, traffic with its staleness flag, the event-timed figure beside it), parity of the kernel that is
+    timed, the boundary block (producer latency under a reading consumer, PCIe-inclusive rate) and the same region in the
+    default environment (no extra hardware queues)."""
+    j = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--launches-per-step", "64", "--no-cpu-baseline"], timeout=900)
+    assert REQUIRED <= set(j) and j["n_gpus"] == 1 and j["value"] > 1e7 and j["scaling"] == "weak" and j["dtype"] == "f32"
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["frac_event_timed"] > 0 and r["algorithmic_bytes_per_launch"] == 4096 * 4100
+    assert r["traffic_source"] is None or isinstance(r["traffic_source"]["matches_this_build"], bool)
+    assert (r["frac_rocprof"] is not None) == bool(r["traffic_source"] and r["traffic_source"]["matches_this_build"])
+    assert r["second_roof"]["bound"] == "valu_issue"
+    assert j["parity"]["kernel"] == "Cfg1024" and j["parity"]["fused_image_pixels_differing_from_two_kernel_image"] == 0
+    b = j["boundary"]
+    assert b["process_block_latency"]["ring_bit_identical_to_undisturbed_batch_run"] is True and b["process_block_latency"]["p50_us"] < 100.0
+    assert b["pcie_inclusive_rate"]["host_memory"]["pinned"]["frames_per_s"] > 1e6
+    d = j["config"]["same_region_default_environment"]
+    assert d["value"] > 1e7 and "unset" in d["GPU_MAX_HW_QUEUES"]
+    assert "jsg_stft_db_launch_batches" in j["config"]["issue"]
