@@ -533,3 +533,41 @@ def test_image_launch_error_paths_return_codes(jsg, oracle, torch_cuda):
     assert lib.jsg_stft_image_launch(plan._p, C.byref(a), None) == cap.JSG_ERR_INVALID
     torch.cuda.synchronize()
     assert not img.any()      # nothing was launched
+
+
+@pytest.mark.parametrize("cfg", ["c2", "c3", "c5"])
+def test_full_launch_every_bin_against_float64_fft(jsg, oracle, torch_cuda, cfg):
+    """Every bin of every column of the BASELINE launches (not a sample of columns) against an independent float64 transform
+    of the float32 windowed frames computed on the GPU (torch.fft.rfft, i.e. rocFFT in double precision -- a checker only, never
+    on the product path), with the reference's float32 channel mix (Spectrogram.cpp:68-76): the bound of tests/parity_util.py,
+    plain 5e-6 within 20 dB of the frame peak, and linearity of the mix."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from parity_util import REL, STRONG_REL, floor_for
+    torch = torch_cuda
+    c = bench.CONFIGS[cfg]
+    n, hop, C, F = c["n"], c["hop"], c["channels"], c["frames"]
+    H = n // 2 + 1
+    win = jsg.window(jsg.capi.WIN_HANN, n)
+    plan = jsg.Plan(n, win)
+    x = torch.from_numpy(bench.synth_audio(C, F * hop + (n - hop), fs=c["fs"], seed=4321)).cuda()
+    d_pow = torch.empty((F, (H + 31) // 32 * 32), device="cuda")
+    jsg.stft_db(plan, x, hop, F, d_pow, feedblocks=n // hop, mix_mode=jsg.capi.MIX_ABSMEAN, linear_out=True)
+    w32 = torch.from_numpy(win).cuda()
+    acc = torch.zeros((F, H), dtype=torch.float32, device="cuda")
+    for ch in range(C):                                     # channel by channel: float32 sum in channel order, like the reference
+        fr = (x[ch].unfold(0, n, hop)[:F] * w32).to(torch.float64)          # float32 product, then exact in float64
+        X = torch.fft.rfft(fr, dim=-1)
+        acc = acc + (X.real * X.real + X.imag * X.imag).to(torch.float32)
+        del fr, X
+    ref = (acc / np.float32(C)).to(torch.float64)
+    got = d_pow[:, :H].to(torch.float64)
+    torch.cuda.synchronize()
+    peak = ref.max(dim=1, keepdim=True).values
+    err = (got - ref).abs()
+    # the float32 rounding of the reference's own per-channel powers and of their sum is part of `ref`: allow it (C + 1 roundings)
+    tol = REL * ref + (floor_for(H) + (C + 1) * 6e-8) * peak
+    assert bool((err <= tol).all()), float((err / tol).max())
+    strong = ref > 1e-2 * peak
+    assert float((err[strong] / ref[strong]).max()) <= STRONG_REL + (C + 1) * 6e-8
