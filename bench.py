@@ -10,15 +10,16 @@ A step is a FIXED, stated group of launches of the fused kernel over synthetic b
 result does not depend on how many steps the driver asks for:
 
   c2 (default, BASELINE.json configs[1]): one step = 1024 launches x 4096 frames (mono 48 kHz, 1024-point FFT, hop 512,
-      Hann) = 4 194 304 frames.  The launches of a step are independent batches; they are issued by ONE C call
-      (jsg_stft_db_launch_many_threads) round-robin over 4 HIP streams, each on its own hardware queue
-      (GPU_MAX_HW_QUEUES=8, set below unless the caller set it), so the ramp-up and drain of one launch overlap the others.  `value` = frames of all ranks / wall time of the K steps.
+      Hann) = 4 194 304 frames.  The launches of a step are independent batches; they are handed to the library in ONE call,
+      jsg_stft_db_launch_batches: stream-ordered with respect to the caller's stream like a single launch, spread over the
+      caller's stream plus three streams of the library and issued by two host threads, so the ramp-up and drain of one launch
+      overlap the others (include/jsg.h).  `value` = frames of all ranks / wall time of the K steps.
+      `--streams N` instead issues over N caller-owned streams (jsg_stft_db_launch_many_threads) -- sweeps and the tracer.
   c3 (configs[2]): one step = 64 launches x 4096 columns of 8-channel 2048-point frames, 75 % overlap, AbsMean mix,
-      issued like c2 over 2 streams.
+      through the same call (two working streams: these kernels run one workgroup per CU).
   c5 (configs[4]): one step = 128 launches x 1875 columns, stereo 96 kHz, 4096-point FFT, 87.5 % overlap, fused
-      STFT -> palette index -> ARGB image (jsg_stft_image_launch).  The images of a step are independent; they are
-      replayed from three hipGraphs on three streams (image i on stream i % 3), so the colour kernel of one image runs
-      beside the STFT kernel of the next.
+      STFT -> palette index -> ARGB image (jsg_stft_image_launch; ONE kernel per image at this size).  The images of a step
+      are independent; they are replayed from three hipGraphs on three streams (image i on stream i % 3).
   `--streams 1` times every configuration in order on one stream (that is also what `roofline` reports, see below).
 
 The batches rotate over ~1 GB of distinct buffers (about four times the 256 MiB Infinity Cache; `--nbuf` overrides), so every
