@@ -99,6 +99,8 @@ static const Config kConfigs[] = {
     {"c4", 1024, 512, 8, 4096, JSG_MIX_PER_CHANNEL, false},// configs[3] shard: 8 ch per GPU, per-channel columns
     {"c5", 4096, 512, 2, 1875, JSG_MIX_ABSMEAN, true},     // configs[4]: stereo, 87.5 % overlap, 10 s ring -> ARGB
     {"big", 1024, 512, 1, 65536, JSG_MIX_ABSMEAN, false},  // asymptotic rate of the 1024-point plan
+    {"c5wide", 4096, 512, 2, 30000, JSG_MIX_ABSMEAN, true},  // sixteen C5 images' worth of columns in one image: what the one-round launch of C5 costs
+    {"c5wide", 4096, 512, 2, 7500, JSG_MIX_ABSMEAN, true},
     {"s1024", 1024, 512, 2, 4096, JSG_MIX_ABSMEAN, false},  // the plugin's stereo bus at 1024 points (mixed kernel instantiation)
     {"s1024", 1024, 512, 2, 32768, JSG_MIX_ABSMEAN, false},
     {"s1024", 1024, 512, 8, 8192, JSG_MIX_ABSMEAN, false},
