@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define JSG_ABI_VERSION 3   /* 3: + kernel-name query, launch pool, image scratch query, sharded set (round 3) */
+#define JSG_ABI_VERSION 4   /* 3: + kernel-name query, launch pool, image scratch query, sharded set; 4: + strided image batches (round 3) */
 
 typedef enum jsg_status {
     JSG_OK = 0,
@@ -229,6 +229,18 @@ typedef struct jsg_stft_image_args {
 } jsg_stft_image_args;
 int jsg_stft_image_launch(const jsg_plan* plan, const jsg_stft_image_args* args, void* stream);
 int jsg_stft_image_needs_scratch(const jsg_plan* plan, const jsg_stft_image_args* args);
+/* `n_images` images of ONE geometry from one call (a batch of independent streams, or the pages of a long recording): `args`
+ * describes one image; image i reads args->stft.in + i * in_image_stride (floats, >= 0) and writes args->colour.argb_out +
+ * i * argb_image_stride (pixels, >= height * argb_pitch).  Where the single-kernel form applies to a launch of the TOTAL size
+ * (1024 points; 4096 points when all images together fill the one-workgroup-per-CU kernel's rounds, or plan_select = 2) the images
+ * share ONE kernel launch whose workgroups walk through the columns of all of them: tables loaded once, the next columns in flight
+ * while the current ones are transformed, no idle workgroup slots at the end of every image (C5, 1875 columns = 235 groups of
+ * eight on 256 CUs: see DESIGN.md 4.4 for the measured gain).  Pixels: those of n_images jsg_stft_image_launch calls with plan_select pinned to the
+ * plan the whole launch takes (the plan rule looks at the total column count).  Otherwise: n_images launches in stream order,
+ * which need `index_scratch` like a single one (jsg_stft_image_strided_needs_scratch tells).  colour.index_out must be NULL. */
+int jsg_stft_image_launch_strided(const jsg_plan* plan, const jsg_stft_image_args* args, int n_images, int64_t in_image_stride,
+                                  int64_t argb_image_stride, void* stream);
+int jsg_stft_image_strided_needs_scratch(const jsg_plan* plan, const jsg_stft_image_args* args, int n_images);
 
 /* ------------------------------------------------------------------------------------------------
  * 3. Engine: the state of class Spectrogram (Spectrogram.h:81-169) living on the GPU.

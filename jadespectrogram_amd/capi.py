@@ -76,6 +76,8 @@ SIGNATURES = {
     "jsg_colormap_launch": (C.c_int, [C.POINTER(ColormapArgs), _P]),
     "jsg_stft_image_launch": (C.c_int, [_P, C.POINTER(StftImageArgs), _P]),
     "jsg_stft_image_needs_scratch": (C.c_int, [_P, C.POINTER(StftImageArgs)]),
+    "jsg_stft_image_launch_strided": (C.c_int, [_P, C.POINTER(StftImageArgs), C.c_int, C.c_int64, C.c_int64, _P]),
+    "jsg_stft_image_strided_needs_scratch": (C.c_int, [_P, C.POINTER(StftImageArgs), C.c_int]),
     "jsg_db_from_power_launch": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
     "jsg_create": (C.c_int, [C.POINTER(_P), C.c_int]),
     "jsg_create_on_device": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int]),

@@ -309,18 +309,21 @@ struct IndexOut {   // fused display path: where and how the palette indices of 
     long long argb_pitch;
     const int* lut;
     int x_first, x_wrap;
+    // ... of `n_images` images of this geometry (single-kernel path; 1: the plain jsg_stft_image_launch)
+    int n_images = 1;
+    long long in_image_stride = 0, argb_image_stride = 0;
 };
 }  // namespace
 
 // 2048 / 4096 points: does this launch take the "B" kernel?  (nc: channels combined into one column)
-static bool wants_plan_b(int n, const jsg_stft_args* g, int nc, int n_cu) {
+static bool wants_plan_b(int n, const jsg_stft_args* g, int nc, int n_cu, long long frames_of_launch = -1) {   // (-1: g->n_frames)
     if (n != 2048 && n != 4096) return false;
     static const int forced2048 = [] { const char* e = getenv("JSG_2048_PLAN"); return e ? atoi(e) : 0; }();   // development A/B: 2 = "B" | 3
     static const int forced4096 = [] { const char* e = getenv("JSG_4096_PLAN"); return e ? atoi(e) : 0; }();
     const int forced = g->plan_select == 1 ? 3 : g->plan_select == 2 ? 2 : (n == 2048 ? forced2048 : forced4096);
     const int tpb_b = n == 2048 ? Cfg2048B::TPB : Cfg4096B::TPB;
     return forced == 2 || (forced != 3 && nc >= (n == 2048 ? k2048B_min_channels : k4096B_min_channels) &&
-                           b_plan_fills_its_rounds(g->n_frames, tpb_b, n_cu));
+                           b_plan_fills_its_rounds(frames_of_launch >= 0 ? frames_of_launch : g->n_frames, tpb_b, n_cu));
 }
 
 static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const IndexOut* io, void* stream) {
@@ -334,7 +337,7 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     if (io && !io->argb && (!io->idx || io->pitch < H || io->n_colors <= 0 || io->n_colors > 256 || g->linear_out))
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch: bad index scratch (needs n_colors <= 256, pitch >= n/2+1, dB mode)");
     if (io && io->argb && (!io->lut || io->n_colors <= 0 || io->n_colors > 256 || io->x_wrap <= 0 || io->x_first < 0 || g->linear_out ||
-                           (plan->n != 1024 && plan->n != 4096)))
+                           (plan->n != 1024 && plan->n != 4096) || io->n_images < 1))
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch: bad image geometry for the single-kernel path");
     if (g->n_frames > g->ring_width)
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: more frames than ring columns in one launch (columns would race)");
@@ -373,6 +376,8 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
         ka.lut = io->lut;
         ka.x_first = io->x_first;
         ka.x_wrap = io->x_wrap;
+        ka.in_image_stride = io->in_image_stride;
+        ka.argb_image_stride = io->argb_image_stride;
         ka.idx = io->idx;
         ka.idx_pitch = io->pitch;
         ka.vmin = io->vmin;
@@ -434,7 +439,16 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
         case 4096: tpb = plan_b ? Cfg4096B::TPB : Cfg4096::TPB; break;
         case 8192: tpb = Cfg8192::TPB; break;
     }
-    const long long want = (g->n_frames + tpb - 1) / tpb;
+    long long want = (g->n_frames + tpb - 1) / tpb;   // workgroup iterations ("groups" of tpb frames) of the launch
+    if (io && io->argb) {   // single-kernel display path: the groups are numbered through the images of the launch
+        const long long gpi = want;
+        want = gpi * io->n_images;
+        if (gpi > (1ll << 20) || want > (1ll << 20))
+            return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_image_launch: more than 2^20 groups of eight columns in one launch");
+        ka.img_gpi = unsigned(gpi);
+        ka.n_groups = unsigned(want);
+        ka.img_magic = ((1ull << 40) + (unsigned long long)gpi - 1) / (unsigned long long)gpi;
+    }
     const int ny = ka.per_channel ? g->channels : 1;
     if (ny > 65535) return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_db_launch: more than 65535 channels in per-channel mode");
     static const int blocks_per_cu_env = [] {   // tuning knob (development): JSG_STFT_BLOCKS_PER_CU
@@ -451,7 +465,7 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     static const int max_blocks_env = [] { const char* e = getenv("JSG_STFT_MAX_BLOCKS"); return e ? atoi(e) : 0; }();   // development
     if (max_blocks_env > 0) max_blocks = max_blocks_env;
     const int nblk = int(want < max_blocks ? want : max_blocks);
-    ka.iters = int((g->n_frames + (long long)nblk * tpb - 1) / ((long long)nblk * tpb));
+    ka.iters = int((want + nblk - 1) / nblk);
     const dim3 grid(nblk, ny);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipError_t err = hipSuccess;
@@ -493,11 +507,12 @@ static int colormap_launch_impl(const jsg_colormap_args* g, const unsigned char*
 // Does jsg_stft_image_launch run as ONE kernel for these arguments?  Where the plan's workgroups hold eight whole columns: 1024
 // points, and 4096 points when the launcher's choice for the launch is the one-wavefront-per-frame kernel ("B": automatic rule or
 // plan_select = 2) -- so the image is always that of jsg_stft_db_launch (same plan_select) + jsg_colormap_launch, bit for bit.
-static bool image_takes_one_kernel(const jsg_plan* plan, const jsg_stft_image_args* g) {
+static bool image_takes_one_kernel(const jsg_plan* plan, const jsg_stft_image_args* g, int n_images = 1) {
     static const int two_kernels = getenv("JSG_IMAGE_TWO_KERNELS") ? 1 : 0;   // development A/B
     const jsg_colormap_args& c = g->colour;
     if (two_kernels || !(plan->n == 1024 || plan->n == 4096) || !c.argb_out || c.index_out || c.n_colors <= 0 || c.n_colors > 256 ||
-        !c.lut || c.x_wrap <= 0 || c.x_first < 0 || c.n_cols > c.x_wrap)
+        !c.lut || c.x_wrap <= 0 || c.x_first < 0 || c.n_cols > c.x_wrap ||
+        (long long)c.height * c.argb_pitch * 4 >= (1ll << 32))   // (the kernel addresses pixels by 32-bit byte offsets from the image's start)
         return false;
     const int mm = g->stft.mix_mode;
     if (mm == JSG_MIX_PER_CHANNEL || mm == JSG_MIX_MAX || mm == JSG_MIX_MIN) return false;
@@ -505,7 +520,8 @@ static bool image_takes_one_kernel(const jsg_plan* plan, const jsg_stft_image_ar
         int dev = -1;
         if (hipGetDevice(&dev) != hipSuccess) return false;
         const int nc = (mm == JSG_MIX_LEFT || mm == JSG_MIX_RIGHT) ? 1 : g->stft.channels;
-        return wants_plan_b(4096, &g->stft, nc, cu_count_of_device(dev));
+        const long long gpi = (g->stft.n_frames + Cfg4096B::TPB - 1) / Cfg4096B::TPB;
+        return wants_plan_b(4096, &g->stft, nc, cu_count_of_device(dev), gpi * Cfg4096B::TPB * n_images);   // (the fill of the whole launch)
     }
     return true;
 }
@@ -513,6 +529,11 @@ static bool image_takes_one_kernel(const jsg_plan* plan, const jsg_stft_image_ar
 int jsg_stft_image_needs_scratch(const jsg_plan* plan, const jsg_stft_image_args* g) {
     if (!plan || !g) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_needs_scratch: null argument");
     return image_takes_one_kernel(plan, g) ? 0 : 1;
+}
+
+int jsg_stft_image_strided_needs_scratch(const jsg_plan* plan, const jsg_stft_image_args* g, int n_images) {
+    if (!plan || !g || n_images < 1) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_strided_needs_scratch: bad argument");
+    return image_takes_one_kernel(plan, g, n_images) ? 0 : 1;
 }
 
 int jsg_stft_image_launch(const jsg_plan* plan, const jsg_stft_image_args* g, void* stream) {
@@ -539,6 +560,42 @@ int jsg_stft_image_launch(const jsg_plan* plan, const jsg_stft_image_args* g, vo
     int rc = stft_launch_impl(plan, &g->stft, &io, stream);
     if (rc != JSG_OK) return rc;
     return colormap_launch_impl(&c, g->index_scratch, (long long)g->index_scratch_pitch, stream);
+}
+
+// `n_images` images of ONE geometry in one call: image i reads stft.in + i * in_image_stride (floats) and writes
+// colour.argb_out + i * argb_image_stride (pixels); everything else in `g` describes one image and holds for all of them.
+// Where jsg_stft_image_launch would take the single-kernel form for a launch of this total size, the images share ONE kernel launch:
+// its workgroups walk through the columns of all images, so the tables are loaded once, the next columns travel while the current
+// ones are transformed, and no workgroup slot idles at the end of an image (C5: 235 eight-column groups per image on 256 CUs).
+// Otherwise the images are launched one after the other on `stream` (two kernels each; `index_scratch` is reused in stream order).
+int jsg_stft_image_launch_strided(const jsg_plan* plan, const jsg_stft_image_args* g, int n_images, int64_t in_image_stride,
+                                  int64_t argb_image_stride, void* stream) {
+    if (!plan || !g) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch_strided: null argument");
+    if (n_images < 0) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch_strided: negative image count");
+    if (n_images == 0 || g->stft.n_frames == 0) return JSG_OK;
+    if (n_images == 1) return jsg_stft_image_launch(plan, g, stream);
+    const jsg_colormap_args& c = g->colour;
+    if (c.ring_width <= 0 || c.col_first < 0 || c.height <= 0 || c.argb_pitch <= 0)
+        return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch_strided: bad colour geometry");
+    if (in_image_stride < 0 || (c.argb_out && argb_image_stride < (long long)c.height * c.argb_pitch))
+        return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch_strided: the images would overlap (argb_image_stride < height * argb_pitch) or a stride is negative");
+    if (c.n_cols != g->stft.n_frames || c.ring_width != g->stft.ring_width || c.height != plan->n / 2 + 1 ||
+        (c.col_first % c.ring_width) != g->stft.ring_pos)
+        return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch_strided: the colour loop must cover exactly the columns of the launch");
+    if (image_takes_one_kernel(plan, g, n_images)) {
+        IndexOut io{nullptr, 0, c.vmin, c.vmax, c.access_mult, c.n_colors, c.argb_out, (long long)c.argb_pitch, c.lut,
+                    c.x_first % c.x_wrap, c.x_wrap, n_images, (long long)in_image_stride, (long long)argb_image_stride};
+        return stft_launch_impl(plan, &g->stft, &io, stream);
+    }
+    for (int i = 0; i < n_images; ++i) {
+        jsg_stft_image_args one = *g;
+        one.stft.in = g->stft.in + (long long)i * in_image_stride;
+        if (one.colour.argb_out) one.colour.argb_out = g->colour.argb_out + (long long)i * argb_image_stride;
+        if (one.colour.index_out) return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_image_launch_strided: index_out planes are not strided (launch the images one by one)");
+        const int rc = jsg_stft_image_launch(plan, &one, stream);
+        if (rc != JSG_OK) return rc;
+    }
+    return JSG_OK;
 }
 
 int jsg_stft_db_launch_many(const jsg_plan* plan, const jsg_stft_args* args, int count, void* const* streams, int n_streams) {

@@ -361,6 +361,13 @@ struct StftKArgs {
     long long argb_pitch;
     const int* lut;               // n_colors entries 0x00RRGGBB
     int x_first, x_wrap;          // column i of the launch lands at x = (x_first + i) % x_wrap
+    // OUTK == 2, several images of one geometry in one launch (jsg_stft_image_launch_strided): the launch's workgroup iterations
+    // ("groups" of TPB columns) are numbered through the images, n_groups = n_images * img_gpi; n_frames stays the columns of ONE image
+    unsigned n_groups;            // groups of the whole launch
+    unsigned img_gpi;             // groups per image = ceil(n_frames / TPB)
+    unsigned long long img_magic; // ceil(2^40 / img_gpi): group / img_gpi == (group * img_magic) >> 40 exactly for group, img_gpi <= 2^20
+    long long in_image_stride;    // floats between the inputs of consecutive images
+    long long argb_image_stride;  // pixels between consecutive images
 };
 
 // dB = 10*log10(p + 1e-11f) -- reference Spectrogram.cpp:107 with g_minValForLogSpectrogram (:36).
@@ -477,8 +484,23 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     const int n_fft = a.iters * nc;   // FFT rounds this wave performs (F frames each), s = it*nc + (c - c0)
     // task (= frame of the launch) of frame f of this lane in iteration `it`; tasks past the end are given the last frame
     // again: they hold the same bits as that frame's own lanes and store them to the same column, so nothing is masked
+    // OUTK == 2: group (= workgroup iteration) `it` of this workgroup -> image and first column inside that image (all scalar).  An
+    // iteration past the last group (last round of the launch) repeats the last group and is not stored (`live` in the store phase).
+    auto group_of = [&](unsigned it, unsigned& image, unsigned& col0) -> bool {
+        unsigned g = (task0 - slot0) / C::TPB + it * (task_stride / C::TPB);
+        const bool inside = g < a.n_groups;
+        if (!inside) g = a.n_groups - 1;
+        image = (unsigned)(((unsigned long long)g * a.img_magic) >> 40);
+        col0 = (g - image * a.img_gpi) * C::TPB;
+        return inside;
+    };
     auto task_of = [&](unsigned it, int f) -> unsigned {
-        unsigned t = task0 + it * task_stride + sub * F + f;
+        unsigned t;
+        if constexpr (OUTK == 2) {
+            unsigned image, col0;
+            group_of(it, image, col0);
+            t = col0 + slot0 + sub * F + f;
+        } else t = task0 + it * task_stride + sub * F + f;
         return t < a.n_frames ? t : a.n_frames - 1;
     };
     auto frame_src = [&](int s, int f) -> const f2u* {
@@ -491,6 +513,11 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         } else {   // the reference's perc10: every fft-size block restarts at offset 0 (Spectrogram.cpp:50-55,216)
             const unsigned blk = j / (unsigned)a.feedblocks;
             start = (long long)blk * C::N + (long long)(j - blk * a.feedblocks) * a.hop;
+        }
+        if constexpr (OUTK == 2) {
+            unsigned image, col0;
+            group_of(it, image, col0);
+            start += (long long)image * a.in_image_stride;
         }
         return reinterpret_cast<const f2u*>(a.in + (long long)c * a.in_pitch + start) + ll;
     };
@@ -538,7 +565,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         tBase = reinterpret_cast<const cf*>(a.tab);
     }
     if constexpr (OUTK == 2) {   // colour table into LDS (n_colors <= 256); it is read after the first workgroup barrier of the store phase
-        if (threadIdx.x < 256) s_lut[threadIdx.x] = a.lut[(int)threadIdx.x < a.n_colors ? (int)threadIdx.x : a.n_colors - 1];
+        if (threadIdx.x < 256) s_lut[threadIdx.x] = a.lut[(int)threadIdx.x < a.n_colors ? (int)threadIdx.x : a.n_colors - 1] | (int)0xFF000000u;   // opaque: pixel = LUT | 0xFF000000
     }
     cf twA[C::TWF ? U2 : 1], twC = {0.f, 0.f};           // TWF: this lane's constant factors (see Cfg)
     int twBrow = 0;
@@ -891,39 +918,57 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                     __syncthreads();
                     {
                         // ---- store phase: every wave-instruction covers 8 consecutive values of ll (rows) x the 8 columns of the
-                        //      iteration: lane = 8 * dl + c reads dword (h, r4, 8 g + dl) of column c and writes four pixels ----
+                        //      iteration: lane = 8 * dl + c reads dword (hr, 8 wave + dl) of column c and writes four pixels.  Wave w takes the
+                        //      items q = w + 8 i (i < 2 P/8), i.e. group g = w of every (half, r4) = hr = i: the LDS reads of a wave are
+                        //      compile-time offsets from one address and its rows step by 64 from value to value, so a pixel costs one
+                        //      32-bit add (byte offsets inside the image: the launcher takes this path for images below 4 GiB only), one
+                        //      palette read and one store.  (Round 3 first had a rolled loop with a 64-bit multiply per pixel and three
+                        //      serial LDS round trips per item: 30 000 columns in one launch 238 us, this form 221-223 us, no store phase
+                        //      at all 174 us -- tools/abbench --cfg c5wide.) ----
                         const int c = lane & 7, dl = lane >> 3;
                         static_assert(C::TPB == 8 && C::WPB == 8, "the store phase is laid out for eight columns per iteration");
-                        const unsigned tcol = task0 - slot0 + it * task_stride + c;   // column c of this iteration (task0 holds this wave's slot)
-                        const bool live = tcol < a.n_frames;
-                        const unsigned* cx = reinterpret_cast<const unsigned*>(smem_raw) + c * D + (SK * c) % 32;
-                        unsigned x = (unsigned)a.x_first + tcol;
-                        x %= (unsigned)a.x_wrap;
-                        unsigned* const img = a.argb + x;
-                        constexpr int ITEMS = 2 * (P / 8) * 8;               // (half, r4, group of eight ll)
-                        for (int q = wave; q < ITEMS; q += C::WPB) {
-                            const int g = q & 7, hr = q >> 3;                // hr = h * (P / 8) + r4
-                            const int r4 = hr % (P / 8);
-                            const bool upper = hr >= P / 8;
-                            const unsigned w4 = cx[hr * 64 + 8 * g + dl];
+                        unsigned image, col0;
+                        const bool inside = group_of(it, image, col0);
+                        const unsigned tcol = col0 + c;                               // column c of this iteration, inside its image
+                        const bool live = inside && tcol < a.n_frames;
+                        const unsigned k0 = 8u * (unsigned)wave + (unsigned)dl;       // this lane's bin of the first value: k = k0 + 64 m
+                        const unsigned* cx = reinterpret_cast<const unsigned*>(smem_raw) + c * D + (SK * c) % 32 + k0;
+                        constexpr int NI = 2 * (P / 8);
+                        unsigned w4[NI];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const int k = 8 * g + dl + 64 * (4 * r4 + j);
-                                const int bin = upper ? M - k : k;
-                                const int rgb = s_lut[(w4 >> (8 * j)) & 0xffu];
-                                // y = H - 1 - bin (Spectrogram.cpp:642).  Plain stores on purpose: a wave-instruction writes 32-byte pieces of eight
-                                // image rows, and the neighbouring workgroups (same XCD: the block remap gives an XCD one contiguous column
-                                // range) write the rest of those 128-byte lines; with the default policy the pieces meet in L2 and leave as
-                                // whole lines, streamed out (non-temporal) every piece went to memory alone: 28.6 vs 22.3 us per C5 image
-                                if (live) img[(long long)(M - bin) * a.argb_pitch] = (unsigned)rgb | 0xFF000000u;
+                        for (int i = 0; i < NI; ++i) w4[i] = cx[i * 64];
+                        const unsigned wNy = cx[(P / 4) * 64 - k0];                   // bin M / 2 of column c (stored by one wave below)
+                        // Only these reads sit between the two workgroup barriers: the indices now live in registers, the exchange regions
+                        // are free again, and the palette reads and the stores below run on the wave's own time, not inside the barrier pair
+                        // (Also tried: the waves 0-3 deferring their pixels into the middle of their next FFT round so that on every SIMD one
+                        // wave's stores lie under the other's arithmetic: 229 vs 221 us)
+                        __syncthreads();
+                        unsigned x = (unsigned)a.x_first + tcol;                      // x_first < x_wrap, tcol < n_frames <= x_wrap (launcher)
+                        if (x >= (unsigned)a.x_wrap) x -= (unsigned)a.x_wrap;
+                        const unsigned pitch4 = (unsigned)a.argb_pitch * 4u, step = 64u * pitch4;
+                        char* const img = reinterpret_cast<char*>(a.argb + (long long)image * a.argb_image_stride);
+                        // y = H - 1 - bin (Spectrogram.cpp:642): the lower half (bin k) walks up the image from row M - k0, the upper half
+                        // (bin M - k) down from row k0.  Plain stores on purpose: a wave-instruction writes 32-byte pieces of eight
+                        // image rows, and the neighbouring workgroups (same XCD: the block remap gives an XCD one contiguous column
+                        // range) write the rest of those 128-byte lines; with the default policy the pieces meet in L2 and leave as
+                        // whole lines, streamed out (non-temporal) every piece went to memory alone: 28.6 vs 22.3 us per C5 image
+                        unsigned oLo = ((unsigned)M - k0) * pitch4 + x * 4u, oUp = k0 * pitch4 + x * 4u;
+                        if (live) {
+#pragma unroll
+                            for (int i = 0; i < NI; ++i) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const unsigned rgb = (unsigned)s_lut[(w4[i] >> (8 * j)) & 0xffu];
+                                    if (i < P / 8) { *reinterpret_cast<unsigned*>(img + oLo) = rgb; oLo -= step; }
+                                    else { *reinterpret_cast<unsigned*>(img + oUp) = rgb; oUp += step; }
+                                }
+                            }
+                            if (wave == C::WPB - 1 && dl == 0) {     // (row M - M / 2)
+                                const unsigned rgb = (unsigned)s_lut[wNy & 0xffu];
+                                *reinterpret_cast<unsigned*>(img + ((unsigned)(M / 2) * pitch4 + x * 4u)) = rgb;
                             }
                         }
-                        if (wave == C::WPB - 1 && dl == 0 && live) {     // bin M / 2 of the eight columns
-                            const int rgb = s_lut[cx[(P / 4) * 64] & 0xffu];
-                            img[(long long)(M - M / 2) * a.argb_pitch] = (unsigned)rgb | 0xFF000000u;
-                        }
                     }
-                    __syncthreads();   // the next round's exchange stores stay behind the reads of the store phase
                 } else if constexpr (OUTK == 1) {
                     // palette index of every bin; 64 consecutive bytes of the index column per store instruction
                     unsigned char* icA = a.idx + (long long)colA * a.idx_pitch;

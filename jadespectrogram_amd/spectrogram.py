@@ -415,6 +415,26 @@ def stft_image_needs_scratch(plan: Plan, d_in, hop: int, n_frames: int, d_lut, l
     return bool(check(lib().jsg_stft_image_needs_scratch(plan._p, C.byref(a))))
 
 
+def stft_image_strided(plan: Plan, d_in, hop: int, n_frames: int, d_lut, lo: float, hi: float, d_argb, d_index_scratch=None, *,
+                       stream: int | None = None, **kw):
+    """`k` images of one geometry from one call (jsg_stft_image_launch_strided): d_in float32 [k][channels][samples], d_argb
+    int32 / uint32 [k][n/2+1][Wimg].  One kernel launch for all of them where the single-kernel form applies to the total size
+    (stft_image_strided_needs_scratch() tells), else k launches in stream order."""
+    import torch
+    assert d_in.dim() == 3 and d_argb.dim() == 3 and d_in.shape[0] == d_argb.shape[0] and d_in.stride(2) == 1 and d_argb.stride(2) == 1
+    a = _stft_image_args(plan, d_in[0], hop, n_frames, d_lut, lo, hi, d_argb[0], d_index_scratch, **kw)
+    if stream is None:
+        stream = torch.cuda.current_stream(d_in.device).cuda_stream
+    check(lib().jsg_stft_image_launch_strided(plan._p, C.byref(a), int(d_in.shape[0]), int(d_in.stride(0)), int(d_argb.stride(0)),
+                                              C.c_void_p(stream)))
+
+
+def stft_image_strided_needs_scratch(plan: Plan, d_in, hop: int, n_frames: int, d_lut, lo: float, hi: float, d_argb, d_index_scratch=None,
+                                     **kw) -> bool:
+    a = _stft_image_args(plan, d_in[0], hop, n_frames, d_lut, lo, hi, d_argb[0], d_index_scratch, **kw)
+    return bool(check(lib().jsg_stft_image_strided_needs_scratch(plan._p, C.byref(a), int(d_in.shape[0]))))
+
+
 def db_from_power(d_power, d_out, divisor: float = 1.0, stream: int | None = None):
     """out = 10*log10(power/divisor + 1e-11f) elementwise on the GPU (finishes a cross-GPU AbsMean)."""
     import torch

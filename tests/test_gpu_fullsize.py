@@ -506,6 +506,96 @@ def test_one_kernel_image_alignments_wraps_and_ragged_widths(jsg, oracle, torch_
     assert int((one == 0x12345678).sum()) == H * (Wimg - F)        # columns the launch does not own keep their pixels
 
 
+@pytest.mark.parametrize("n,C,F,Wimg,x_first,K,sel", [
+    (4096, 2, 1875, 1888, 0, 5, 0),      # C5 images: 5 x 235 groups, the fill rule takes the one-wavefront-per-frame kernel by itself
+    (4096, 2, 1873, 1888, 20, 3, 2),     # ragged last group of every image, wrap in x
+    (4096, 1, 300, 320, 0, 6, 0),        # images that alone would not fill a round: 6 x 38 = 228 groups do (a single one takes two kernels)
+    (1024, 1, 1001, 1004, 0, 4, 0),
+    (1024, 2, 999, 1000, 3, 9, 0),
+    (1024, 2, 8, 8, 0, 33, 0),           # one group per image
+    (1024, 1, 5, 8, 6, 3, 0),            # less than a group per image, wrapping
+])
+def test_strided_image_batch_equals_single_launches(jsg, oracle, torch_cuda, n, C, F, Wimg, x_first, K, sel):
+    """jsg_stft_image_launch_strided: K images of one geometry in ONE kernel launch (the workgroups walk through the columns of all
+    images) give the pixels of K separate launches with the plan pinned, bit for bit; pixels outside the launch's columns and the
+    padding between the images stay untouched."""
+    torch = torch_cuda
+    hop = 512
+    fb = n // hop
+    plan = jsg.Plan(n, oracle.window(oracle.WIN_HANN, n))
+    ns = (F - 1) * hop + n
+    d_in = torch.stack([_stream(torch, C, ns + 64, seed=1000 * n + 17 * k + F) for k in range(K)]).contiguous()   # [K][C][samples]
+    d_in[:, :, ns:] = float("nan")                                     # samples no frame may read
+    H = n // 2 + 1
+    d_lut = torch.from_numpy(jsg.colormap_lut(256, jsg.capi.CM_JADE)).cuda()
+    pin = 2 if n == 4096 else 0                                        # what the batch takes (checked below): the single launches are pinned to it
+    ref = torch.full((K, H + 1, Wimg), 0x12345678, dtype=torch.int32, device="cuda")     # one spare row between the images
+    out = torch.full((K, H + 1, Wimg), 0x12345678, dtype=torch.int32, device="cuda")
+    kw = dict(feedblocks=fb, ring_width=F, x_first=x_first)
+    assert not jsg.stft_image_strided_needs_scratch(plan, d_in, hop, F, d_lut, -60.0, 40.0, out[:, :H], None, plan_select=sel, **kw)
+    for k in range(K):
+        assert not jsg.stft_image_needs_scratch(plan, d_in[k], hop, F, d_lut, -60.0, 40.0, ref[k, :H], None, plan_select=pin, **kw)
+        jsg.stft_image(plan, d_in[k], hop, F, d_lut, -60.0, 40.0, ref[k, :H], None, plan_select=pin, **kw)
+    jsg.stft_image_strided(plan, d_in, hop, F, d_lut, -60.0, 40.0, out[:, :H], None, plan_select=sel, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert int((out == 0x12345678).sum()) == K * (H * (Wimg - F) + Wimg)
+    # and against the unfused pair of kernels for the first and the last image
+    d_db = torch.empty((F, (H + 31) // 32 * 32), device="cuda")
+    for k in (0, K - 1):
+        two = torch.full((H, Wimg), 0x12345678, dtype=torch.int32, device="cuda")
+        jsg.stft_db(plan, d_in[k], hop, F, d_db, feedblocks=fb, plan_select=pin)
+        jsg.colormap(d_db, d_lut, -60.0, 40.0, d_argb=two, x_first=x_first, n_cols=F, height=H)
+        torch.cuda.synchronize()
+        assert torch.equal(out[k, :H], two), k
+
+
+def test_strided_image_batch_fallback_and_error_paths(jsg, oracle, torch_cuda):
+    """Where the single-kernel form does not apply (2048 points; 4096 points pinned to the two-wavefront plan) the strided call is K
+    launches in stream order through the index scratch; overlapping images, negative strides and counts are refused with a code."""
+    import ctypes as C
+    torch = torch_cuda
+    from jadespectrogram_amd.spectrogram import _stft_image_args
+    cap = jsg.capi
+    lib = cap.lib()
+    d_lut = torch.from_numpy(jsg.colormap_lut(256, cap.CM_JADE)).cuda()
+    for n, sel in ((2048, 0), (4096, 1)):
+        hop, F, K, Cn = 512, 130, 3, 2
+        H = n // 2 + 1
+        plan = jsg.Plan(n, oracle.window(oracle.WIN_HANN, n))
+        d_in = torch.stack([_stream(torch, Cn, (F - 1) * hop + n, seed=n + k) for k in range(K)]).contiguous()
+        ref = torch.zeros((K, H, F), dtype=torch.int32, device="cuda")
+        out = torch.zeros((K, H, F), dtype=torch.int32, device="cuda")
+        scratch = torch.zeros((F, (H + 63) // 64 * 64), dtype=torch.uint8, device="cuda")
+        kw = dict(feedblocks=n // hop, plan_select=sel)
+        assert jsg.stft_image_strided_needs_scratch(plan, d_in, hop, F, d_lut, -50.0, 50.0, out, None, **kw)
+        with pytest.raises(jsg.JsgError) as ei:
+            jsg.stft_image_strided(plan, d_in, hop, F, d_lut, -50.0, 50.0, out, None, **kw)
+        assert ei.value.code == cap.JSG_ERR_INVALID and "index_scratch" in str(ei.value)
+        for k in range(K):
+            jsg.stft_image(plan, d_in[k], hop, F, d_lut, -50.0, 50.0, ref[k], scratch, **kw)
+        jsg.stft_image_strided(plan, d_in, hop, F, d_lut, -50.0, 50.0, out, scratch, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref) and bool(out.any())
+    n, hop, F, K = 1024, 512, 64, 4
+    H = n // 2 + 1
+    plan = jsg.Plan(n, oracle.window(oracle.WIN_HANN, n))
+    d_in = torch.stack([_stream(torch, 1, (F - 1) * hop + n, seed=k) for k in range(K)]).contiguous()
+    out = torch.zeros((K, H, F), dtype=torch.int32, device="cuda")
+    a = _stft_image_args(plan, d_in[0], hop, F, d_lut, -50.0, 50.0, out[0], None, feedblocks=2)
+    call = lambda k, si, so: lib.jsg_stft_image_launch_strided(plan._p, C.byref(a), k, si, so, None)
+    assert call(-1, d_in.stride(0), out.stride(0)) == cap.JSG_ERR_INVALID
+    assert call(K, -1, out.stride(0)) == cap.JSG_ERR_INVALID
+    assert call(K, d_in.stride(0), out.stride(0) - 1) == cap.JSG_ERR_INVALID      # images would overlap
+    assert call(0, 0, 0) == cap.JSG_OK
+    assert lib.jsg_stft_image_strided_needs_scratch(plan._p, C.byref(a), 0) == cap.JSG_ERR_INVALID
+    torch.cuda.synchronize()
+    assert not out.any()                                                           # nothing was launched
+    assert call(K, d_in.stride(0), out.stride(0)) == cap.JSG_OK
+    torch.cuda.synchronize()
+    assert bool(out[K - 1].any())
+
+
 def test_image_launch_error_paths_return_codes(jsg, oracle, torch_cuda):
     """nothing fatal crosses the C boundary.  ring_width = 0 in both halves of the image arguments used to reach a
     modulo by zero (SIGFPE in the host process); a launch that needs the index scratch says so instead of dereferencing NULL."""
