@@ -17,9 +17,11 @@ result does not depend on how many steps the driver asks for:
       `--streams N` instead issues over N caller-owned streams (jsg_stft_db_launch_many_threads) -- sweeps and the tracer.
   c3 (configs[2]): one step = 64 launches x 4096 columns of 8-channel 2048-point frames, 75 % overlap, AbsMean mix,
       through the same call (two working streams: these kernels run one workgroup per CU).
-  c5 (configs[4]): one step = 128 launches x 1875 columns, stereo 96 kHz, 4096-point FFT, 87.5 % overlap, fused
-      STFT -> palette index -> ARGB image (jsg_stft_image_launch; ONE kernel per image at this size).  The images of a step
-      are independent; they are replayed from three hipGraphs on three streams (image i on stream i % 3).
+  c5 (configs[4]): independent images of 1875 columns (10 s), stereo 96 kHz, 4096-point FFT, 87.5 % overlap, fused STFT ->
+      palette index -> ARGB image in ONE kernel.  The images have one geometry and lie at a fixed stride, so a step hands them to the
+      library as strided batches (jsg_stft_image_launch_strided): one step = 3 launches x a whole rotation of images (~39) =
+      ~117 images; the workgroups of a launch walk through the columns of all its images.  `--images-per-launch 1 [--streams S]`
+      launches the images one by one instead (jsg_stft_image_launch; 128 per step, three hipGraphs on three streams by default).
   `--streams 1` times every configuration in order on one stream (that is also what `roofline` reports, see below).
 
 The batches rotate over ~1 GB of distinct buffers (about four times the 256 MiB Infinity Cache; `--nbuf` overrides), so every
@@ -64,10 +66,10 @@ CONFIGS = {
     "c3": dict(n=2048, hop=512, channels=8, frames=4096, fs=48000.0, colour=False, launches_per_step=64, streams=2,
                metric="STFT frames/sec (2048-pt, 75% overlap, 8 channels mixed to one column)", unit="frames/s",
                workload="configs[2]: 8-channel 48 kHz, 2048-pt FFT, 512 hop (75 % overlap), Hann, AbsMean mix, 4096 columns/launch"),
-    "c5": dict(n=4096, hop=512, channels=2, frames=1875, fs=96000.0, colour=True, launches_per_step=128, streams=3,
+    "c5": dict(n=4096, hop=512, channels=2, frames=1875, fs=96000.0, colour=True, launches_per_step=128, streams=3, batch_launches_per_step=3,
                metric="STFT->ARGB columns/sec (4096-pt, 87.5% overlap, stereo 96 kHz)", unit="columns/s",
                workload="configs[4]: stereo 96 kHz, 4096-pt FFT, 512 hop (87.5 % overlap), AbsMean, Jade LUT -50..50 dB -> ARGB image, "
-                        "1875 columns (10 s) per launch, fused STFT -> palette index -> ARGB"),
+                        "independent images of 1875 columns (10 s), fused STFT -> palette index -> ARGB"),
 }
 
 
@@ -316,6 +318,8 @@ def main():
     ap.add_argument("--launches-per-step", type=int, default=0, help="launches in one step (default: the configuration's)")
     ap.add_argument("--nbuf", type=int, default=0, help="distinct batches rotated through (default: enough for > 256 MiB)")
     ap.add_argument("--streams", type=int, default=0, help="HIP streams of the timed region (default: 4 for c2, 2 for c3, 3 for c5; 1 = in order)")
+    ap.add_argument("--images-per-launch", type=int, default=0, help="c5: images of one jsg_stft_image_launch_strided call (default: the whole rotation, "
+                                                                     "~39; 1 = one jsg_stft_image_launch per image, on --streams streams)")
     ap.add_argument("--issue-threads", type=int, default=2, help="host threads issuing the launches of a step (c2, streams > 1)")
     ap.add_argument("--blocks-per-cu", type=int, default=1, help="workgroups per CU of each launch when launches overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -329,8 +333,11 @@ def main():
                                                            "JSON) on a machine without GPUs; value is null")
     args = ap.parse_args()
     c = dict(CONFIGS[args.config])
-    lps = args.launches_per_step or c["launches_per_step"]
-    n_streams = max(1, args.streams or c["streams"])
+    # c5: the images of a step are independent and of one geometry -> by default they go to the library as strided batches, one kernel
+    # launch for a whole rotation of images (jsg_stft_image_launch_strided); --images-per-launch 1 (or --streams > 1) launches them one by one
+    batch = bool(c["colour"]) and args.images_per_launch != 1 and args.streams <= 1
+    lps = args.launches_per_step or (c["batch_launches_per_step"] if batch else c["launches_per_step"])
+    n_streams = 1 if batch else max(1, args.streams or c["streams"])
 
     import numpy as np
     import torch
@@ -394,6 +401,7 @@ def main():
     units_per_launch = F if c["colour"] else F * C     # columns for c5, frames (FFTs) otherwise
 
     run_step = None
+    ipl, nrot = 1, 0                                  # images per launch (c5 batches), distinct launch argument sets
     inorder_us = eager_us = None
     copy_us = None
     parity = None
@@ -409,26 +417,43 @@ def main():
         pitch = (H + 31) // 32 * 32
         idx_pitch = (H + 63) // 64 * 64
         img_pitch = (F + 31) // 32 * 32
-        per_batch = C * n_samples * 4 + (F * idx_pitch + H * img_pitch * 4 if c["colour"] else F * pitch * 4)
+        per_batch = C * n_samples * 4 + ((0 if batch else F * idx_pitch) + H * img_pitch * 4 if c["colour"] else F * pitch * 4)
         # Rotation: distinct batches worth ~1 GB, about four times the 256 MiB Infinity Cache.  (Rounds 1-2 rotated over 0.3 GB; the
         # --nbuf sweep of round 3 -- profiles/r03_c2_nbuf_sweep.json -- showed that a good part of those reads still hit the cache:
         # C2 1.35e9 frames/s at 0.35 GB, 1.12e9 at 0.7 GB, 1.10e9 at 1.4 GB.)
         nbuf = args.nbuf or max(2, int(ROTATION_BYTES // per_batch) + 1)
         while n_streams > 1 and nbuf % n_streams:   # a batch must always land on the same stream (its ring is rewritten in order)
             nbuf += 1
+        if batch:                                   # the rotation is cut into launches of `ipl` images each
+            ipl = min(args.images_per_launch or nbuf, nbuf)
+            nbuf = (nbuf + ipl - 1) // ipl * ipl
+            nrot = nbuf // ipl
+            algo *= ipl
+            units_per_launch *= ipl
         base = synth_audio(C, n_samples + nbuf * 64, fs=c["fs"], seed=1234 + 1000 * rank)   # SURVEY 8d signal
         d_in, d_out, d_img, d_scr = [], [], [], []
+        d_in_all = torch.empty((nbuf, C, n_samples), dtype=torch.float32, device="cuda")      # contiguous: image b = d_in_all[b] (strided launches)
+        d_img_all = torch.zeros((nbuf, H, img_pitch), dtype=torch.int32, device="cuda") if c["colour"] else None
         for b in range(nbuf):
-            d_in.append(torch.from_numpy(np.ascontiguousarray(base[:, b * 64:b * 64 + n_samples])).cuda())
+            d_in_all[b].copy_(torch.from_numpy(np.ascontiguousarray(base[:, b * 64:b * 64 + n_samples])))
+            d_in.append(d_in_all[b])
             if c["colour"]:
-                d_img.append(torch.zeros((H, img_pitch), dtype=torch.int32, device="cuda"))
-                d_scr.append(torch.zeros((F, idx_pitch), dtype=torch.uint8, device="cuda"))
+                d_img.append(d_img_all[b])
+                d_scr.append(torch.zeros((F, idx_pitch), dtype=torch.uint8, device="cuda") if not batch else None)
             else:
                 d_out.append(torch.empty((F, pitch), dtype=torch.float32, device="cuda"))
+        if not batch:
+            nrot = nbuf
         d_lut = torch.from_numpy(jsg.colormap_lut(256, jsg.capi.CM_JADE)).cuda() if c["colour"] else None
         fb = n // hop
         kernel_label = None
-        if c["colour"]:
+        if batch:
+            two = jsg.stft_image_strided_needs_scratch(plan, d_in_all[:ipl], hop, F, d_lut, -50.0, 50.0, d_img_all[:ipl, :, :F], None, feedblocks=fb,
+                                                       mix_mode=jsg.capi.MIX_ABSMEAN)
+            assert not two, "the strided C5 launch is expected to take the single-kernel form"
+            kernel_label = (f"stft_db_kernel<Cfg4096B, AbsMean, ARGB out> (jsg_stft_image_launch_strided: {ipl} images in one kernel launch, "
+                            "the workgroups colour their columns)")
+        elif c["colour"]:
             two = jsg.stft_image_needs_scratch(plan, d_in[0], hop, F, d_lut, -50.0, 50.0, d_img[0][:, :F], d_scr[0], feedblocks=fb,
                                                mix_mode=jsg.capi.MIX_ABSMEAN)
             kernel_label = ("stft_db_kernel<4096, AbsMean, index out> + colormap_kernel (jsg_stft_image_launch, two kernels)" if two else
@@ -436,7 +461,10 @@ def main():
         one = torch.cuda.Stream()
 
         def launch(b, stream_handle, bpc=0):
-            if c["colour"]:
+            if batch:       # launch b of the rotation: images [b * ipl, (b + 1) * ipl)
+                jsg.stft_image_strided(plan, d_in_all[b * ipl:(b + 1) * ipl], hop, F, d_lut, -50.0, 50.0, d_img_all[b * ipl:(b + 1) * ipl, :, :F], None,
+                                       feedblocks=fb, mix_mode=jsg.capi.MIX_ABSMEAN, stream=stream_handle)
+            elif c["colour"]:
                 jsg.stft_image(plan, d_in[b], hop, F, d_lut, -50.0, 50.0, d_img[b][:, :F], d_scr[b], feedblocks=fb,
                                mix_mode=jsg.capi.MIX_ABSMEAN, stream=stream_handle)
             else:
@@ -445,7 +473,7 @@ def main():
 
         # ---- the in-order group of one step as a hipGraph on ONE stream (per-kernel view; the timed region of c3 / c5) ----
         with torch.cuda.stream(one):
-            for b in range(min(nbuf, lps)):
+            for b in range(min(nrot, lps)):
                 launch(b, one.cuda_stream)
             torch.cuda.synchronize()
         gate = {"cycles_per_ms": 0.0, "cycles": 0}
@@ -478,7 +506,7 @@ def main():
             if c["colour"]:
                 def _issue():
                     for i in range(lps):
-                        launch(i % nbuf, one.cuda_stream)
+                        launch(i % nrot, one.cuda_stream)
                 replay_inorder = gated(_issue)
             else:
                 arr1 = (capi.StftArgs * lps)()
@@ -493,7 +521,7 @@ def main():
             with torch.cuda.stream(one):
                 with torch.cuda.graph(graph, stream=one):
                     for i in range(lps):
-                        launch(i % nbuf, one.cuda_stream)
+                        launch(i % nrot, one.cuda_stream)
             torch.cuda.synchronize()
 
             def replay_inorder():
@@ -598,7 +626,7 @@ def main():
                     ev0.record(one)
                     if c["colour"]:
                         for i in range(lps):
-                            launch(i % nbuf, one.cuda_stream)
+                            launch(i % nrot, one.cuda_stream)
                     else:
                         capi.check(lib.jsg_stft_db_launch_many(plan._p, arr1, lps, one_arr, 1))
                     ev1.record(one)
@@ -617,11 +645,11 @@ def main():
             k = min(lps, 512)
             with torch.cuda.stream(one):
                 for i in range(64):
-                    launch(i % nbuf, one.cuda_stream)
+                    launch(i % nrot, one.cuda_stream)
                 torch.cuda.synchronize()
                 ev0.record(one)
                 for i in range(k):
-                    launch(i % nbuf, one.cuda_stream)
+                    launch(i % nrot, one.cuda_stream)
                 ev1.record(one)
             torch.cuda.synchronize()
             eager_us = ev0.elapsed_time(ev1) * 1e3 / k
@@ -635,14 +663,14 @@ def main():
         # context for the roofline: a plain device-to-device copy of the SAME byte count, same rotation, same graph timing --
         # what a launch of this size can reach at all on this GPU
         nflt = algo // 8
-        csrc = [torch.rand(nflt, device="cuda") for _ in range(nbuf)]
-        cdst = [torch.empty(nflt, device="cuda") for _ in range(nbuf)]
+        csrc = [torch.rand(nflt, device="cuda") for _ in range(nrot)]
+        cdst = [torch.empty(nflt, device="cuda") for _ in range(nrot)]
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.stream(one):
             cdst[0].copy_(csrc[0]); torch.cuda.synchronize()
             with torch.cuda.graph(g2, stream=one):
                 for i in range(min(lps, 256)):
-                    cdst[i % nbuf].copy_(csrc[i % nbuf])
+                    cdst[i % nrot].copy_(csrc[i % nrot])
             g2.replay(); torch.cuda.synchronize()
             c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             c0.record(one)
@@ -654,17 +682,45 @@ def main():
         del csrc, cdst, g2
     if rank == 0 and not args.dry_run and world == 1:
         parity = parity_report(jsg, c, plan, base, win)
+        if batch:   # the timed strided launch against one-by-one launches of the same images (same kernel plan), three images of the batch
+            with torch.cuda.stream(one):
+                launch(0, one.cuda_stream)
+                tmp = torch.zeros((H, img_pitch), dtype=torch.int32, device="cuda")
+                differing = 0
+                for k in sorted({0, ipl // 2, ipl - 1}):
+                    tmp.zero_()
+                    jsg.stft_image(plan, d_in[k], hop, F, d_lut, -50.0, 50.0, tmp[:, :F], None, feedblocks=fb, mix_mode=jsg.capi.MIX_ABSMEAN,
+                                   plan_select=2, stream=one.cuda_stream)
+                    differing += int((tmp != d_img_all[k]).sum())
+            parity["strided_batch_pixels_differing_from_single_launches"] = differing
 
     units_total = world * args.steps * lps * units_per_launch
+    gate_note = " (the gate is inside the timed region: this mode is for the tracer)"
+    if batch:
+        issue_text = ("strided batches of independent images, one kernel launch per batch (jsg_stft_image_launch_strided), "
+                      + ("host-issued" if args.no_graph else "hipGraph replay") + ", in order on one stream")
+    elif n_streams == 1:
+        issue_text = ("hipGraph replay, in order" if not args.no_graph else
+                      "host-issued behind a gate kernel, in order and back to back on one stream" + gate_note if args.gate else "host-issued, in order on one stream")
+    elif c["colour"]:
+        issue_text = f"{n_streams} hipGraphs per step (independent images, one stream each), replayed together"
+    else:
+        issue_text = ("one jsg_stft_db_launch_batches call per step on one caller stream: the library forks onto its own streams (4; 2 for the "
+                      "one-workgroup-per-CU kernels), issues from 2 host threads and joins" if (not args.streams and not args.gate) else
+                      f"one C call per step, {max(1, args.issue_threads)} host thread(s)")
+        if args.gate:
+            issue_text += ", every stream held by a gate kernel while the host enqueues the step" + gate_note
     out = {
         "metric": c["metric"], "value": None if args.dry_run else units_total / wall, "unit": c["unit"],
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": c["workload"],
-                   "step": f"{lps} launches x {F} {'columns' if c['colour'] or C > 1 else 'frames'} = {lps * units_per_launch} {c['unit'].split('/')[0]} per step and GPU",
-                   "launches_per_step": lps, "frames_per_launch": F * C, "columns_per_launch": F, "channels_per_gpu": C,
+                   "step": (f"{lps} launches x {ipl} images x {F} columns = {lps * units_per_launch} columns per step and GPU" if batch else
+                            f"{lps} launches x {F} {'columns' if c['colour'] or C > 1 else 'frames'} = {lps * units_per_launch} {c['unit'].split('/')[0]} per step and GPU"),
+                   "launches_per_step": lps, "images_per_launch": ipl if c["colour"] else None, "frames_per_launch": F * C * ipl, "columns_per_launch": F * ipl,
+                   "channels_per_gpu": C,
                    "distinct_batches": nbuf, "hip_streams_per_gpu": n_streams, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
-                   "issue": ((("host-issued behind a gate kernel, in order and back to back on one stream (the gate is inside the timed region: this mode is for the tracer)" if args.gate else "host-issued, in order on one stream") if args.no_graph else "hipGraph replay, in order") if n_streams == 1 else (f"{n_streams} hipGraphs per step (independent images, one stream each), replayed together" if c["colour"] else ("one jsg_stft_db_launch_batches call per step on one caller stream: the library forks onto its own streams (4; 2 for the one-workgroup-per-CU kernels), issues from 2 host threads and joins" if (not args.streams and not args.gate) else f"one C call per step, {max(1, args.issue_threads)} host thread(s)") + (", every stream held by a gate kernel while the host enqueues the step (the gates are inside the timed region: this mode is for the tracer)" if args.gate else ""))),
+                   "issue": issue_text,
                    "prewarm_s": round(prewarm_s, 3),
                    "parallelism": f"{world} GPU(s), independent batches, no data-path collective"},
     }
@@ -682,7 +738,7 @@ def main():
         if os.path.exists(prof):
             try:
                 pj = json.load(open(prof))
-                same = pj.get("kernel_source_sha") == kernel_source_sha()
+                same = pj.get("kernel_source_sha") == kernel_source_sha() and int(pj.get("images_per_launch") or 1) == ipl
                 traffic = pj.get("hbm_bytes_per_launch")
                 rocprof_us = pj.get("avg_us") if same else None
                 tsrc = {"file": os.path.relpath(prof, ROOT), "recorded_at_commit": pj.get("commit"), "kernel_source_sha": pj.get("kernel_source_sha"),

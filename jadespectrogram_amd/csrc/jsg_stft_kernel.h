@@ -385,6 +385,22 @@ __device__ __forceinline__ int color_index(float v, float vmin, float vmax, floa
     return idx < n_colors ? idx : n_colors - 1;
 }
 
+// The same for the two values of a packed pair: the subtraction and the multiplication as one packed instruction each (same
+// roundings), the lower clamp as v_max_f32 (a NaN ends at index 0 either way: v_cvt_i32_f32(NaN) = 0).  12 instead of 16
+// instructions per pair; the display kernels spend them on every bin.
+__device__ __forceinline__ void color_index2(cf v, float vmin, float vmax, float top, float mult, int n_colors, int& ix, int& iy) {
+    v.x = v.x >= vmax ? top : v.x;
+    v.y = v.y >= vmax ? top : v.y;
+    // (written out: for __builtin_fmaxf the compiler first quiets a possible signalling NaN with a second v_max_f32 per value)
+    asm("v_max_f32 %0, %1, %2" : "=v"(v.x) : "v"(v.x), "s"(vmin));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v.y) : "v"(v.y), "s"(vmin));
+    const cf t = (v - cf{vmin, vmin}) * cf{mult, mult};
+    ix = (int)t.x;
+    iy = (int)t.y;
+    ix = ix < n_colors ? ix : n_colors - 1;
+    iy = iy < n_colors ? iy : n_colors - 1;
+}
+
 template <int MIXOP>
 __device__ __forceinline__ float mix_combine(float acc, float pw) {
     if constexpr (MIXOP == 0) return acc + pw;                  // AbsMean / Sum: m_powerfinal += m_power[cc]  (:72)
@@ -908,8 +924,10 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                         unsigned wx = 0, wy = 0;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            wx |= (unsigned)color_index(acc[f][4 * r4 + j].x, a.vmin, a.vmax, a.top, a.mult, a.n_colors) << (8 * j);
-                            wy |= (unsigned)color_index(acc[f][4 * r4 + j].y, a.vmin, a.vmax, a.top, a.mult, a.n_colors) << (8 * j);
+                            int ix_, iy_;
+                            color_index2(acc[f][4 * r4 + j], a.vmin, a.vmax, a.top, a.mult, a.n_colors, ix_, iy_);
+                            wx |= (unsigned)ix_ << (8 * j);
+                            wy |= (unsigned)iy_ << (8 * j);
                         }
                         ix[r4 * 64 + ll] = wx;
                         ix[(P / 8 + r4) * 64 + ll] = wy;
@@ -978,8 +996,10 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                     for (int rho = 0; rho < P / 2; ++rho) {
                         unsigned char* d = (L == 32 && (rho & 1)) ? icB : icA;
                         const int k = lw + LW * (L == 32 ? rho / 2 : rho);
-                        d[k] = (unsigned char)color_index(acc[f][rho].x, a.vmin, a.vmax, a.top, a.mult, a.n_colors);
-                        d[M - k] = (unsigned char)color_index(acc[f][rho].y, a.vmin, a.vmax, a.top, a.mult, a.n_colors);
+                        int ix_, iy_;
+                        color_index2(acc[f][rho], a.vmin, a.vmax, a.top, a.mult, a.n_colors, ix_, iy_);
+                        d[k] = (unsigned char)ix_;
+                        d[M - k] = (unsigned char)iy_;
                     }
                     if (L <= 64 || ll == 0) ic[M / 2] = (unsigned char)color_index(accNy[f], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
                 } else if (C::ABL == 2 ? (acc[f][0].x == 12345.678f) : true) {

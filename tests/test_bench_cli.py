@@ -63,6 +63,20 @@ def test_other_configs_emit_a_line(cfg, unit):
     assert j["unit"] == unit and j["value"] > 0 and j["roofline"]["algorithmic_bytes_per_launch"] > 0
     assert j["parity"]["max_rel_power_err_bins_within_20dB_of_peak"] < 1e-5
     assert j["parity"]["colour_index_flips_end_to_end"] <= max(4, j["parity"]["pixels_checked"] // 500)
+    if cfg == "c5":   # default: strided batches, one kernel launch for a whole rotation of images; the pixels are those of single launches
+        k = j["config"]["images_per_launch"]
+        assert k > 8 and "jsg_stft_image_launch_strided" in j["config"]["issue"] and j["config"]["launches_per_step"] == 8
+        assert j["roofline"]["algorithmic_bytes_per_launch"] == k * 1875 * 12292
+        assert j["parity"]["strided_batch_pixels_differing_from_single_launches"] == 0
+        assert abs(j["ms_per_step"] * j["steps"] * 1e-3 * j["value"] - 2 * 8 * k * 1875) < 1.0
+
+
+@pytest.mark.gpu
+def test_c5_one_image_per_launch_mode_still_runs():
+    j = _run([sys.executable, "bench.py", "--config", "c5", "--images-per-launch", "1", "--steps", "2", "--warmup", "1", "--launches-per-step", "9",
+              "--no-cpu-baseline", "--no-boundary"])
+    assert j["config"]["images_per_launch"] == 1 and j["config"]["hip_streams_per_gpu"] == 3 and j["value"] > 0
+    assert j["roofline"]["algorithmic_bytes_per_launch"] == 1875 * 12292 and "strided_batch_pixels_differing_from_single_launches" not in j["parity"]
 
 
 @pytest.mark.gpu

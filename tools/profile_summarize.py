@@ -19,8 +19,10 @@ try:
     line = json.loads(open(os.path.join(out_dir, "bench_lines.jsonl")).readline())
     res["bench_line_under_trace"] = {"value": line["value"], "unit": line["unit"], "avg_launch_us": line["roofline"]["avg_launch_us"],
                                      "frac_of_8p0": line["roofline"]["frac_of_8p0"]}
+    ipl = int(line["config"].get("images_per_launch") or 1)       # c5: images of one strided launch (one dispatch)
 except Exception:
-    pass
+    ipl = 1
+res["images_per_launch"] = ipl
 # 1. kernel stats
 main_kernel = "stft_db_kernel"
 for f in glob.glob(os.path.join(out_dir, "stats", "**", "*kernel_stats.csv"), recursive=True):
@@ -60,14 +62,14 @@ if fetch and write:
     res["fetch_bytes_corrected"] = fetch * 1024 * 2
     res["write_bytes"] = write * 1024
     res["hbm_bytes_per_launch"] = res["fetch_bytes_corrected"] + res["write_bytes"]
-    res["algorithmic_bytes_per_launch"] = bench.algorithmic_bytes_per_launch(bench.CONFIGS[cfg])
+    res["algorithmic_bytes_per_launch"] = bench.algorithmic_bytes_per_launch(bench.CONFIGS[cfg]) * ipl
     res["traffic_over_algorithmic"] = res["hbm_bytes_per_launch"] / res["algorithmic_bytes_per_launch"]
     if "avg_us" in res:
         res["frac_of_8p0_from_trace_avg"] = res["algorithmic_bytes_per_launch"] / (res["avg_us"] * 1e-6) / 8e12
 # derived: instructions per FFT and how busy the vector and LDS pipes were (SQ counters are per dispatch means; SQ_WAVE_CYCLES and
 # SQ_ACTIVE_INST_* count quad-cycles summed over the waves, SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES LDS-array / CU cycles)
 c = bench.CONFIGS[cfg]
-ffts = c["frames"] * c["channels"]
+ffts = c["frames"] * c["channels"] * ipl
 for kname, d in res["counters_mean_per_dispatch"].items():
     if "stft_db_kernel" not in kname or "SQ_WAVE_CYCLES" not in d:
         continue
