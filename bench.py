@@ -324,6 +324,7 @@ def main():
     ap.add_argument("--blocks-per-cu", type=int, default=1, help="workgroups per CU of each launch when launches overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sub-run", action="store_true", help="(internal) this process is the default-environment child of another bench.py")
+    ap.add_argument("--no-parity", action="store_true", help="skip the `parity` block (the profile scripts: its few launches would mix into the tracer's averages)")
     ap.add_argument("--no-boundary", action="store_true", help="skip the `boundary` block (jsg_process_block latency, PCIe-inclusive rate)")
     ap.add_argument("--gate", action="store_true", help="with --no-graph: hold the stream with a gate kernel while the host enqueues a step's "
                                                         "launches, so that they run back to back even under a tracer (short kernels: c2)")
@@ -680,7 +681,7 @@ def main():
         torch.cuda.synchronize()
         copy_us = c0.elapsed_time(c1) * 1e3 / (4 * min(lps, 256))
         del csrc, cdst, g2
-    if rank == 0 and not args.dry_run and world == 1:
+    if rank == 0 and not args.dry_run and world == 1 and not args.no_parity:
         parity = parity_report(jsg, c, plan, base, win)
         if batch:   # the timed strided launch against one-by-one launches of the same images (same kernel plan), three images of the batch
             with torch.cuda.stream(one):

@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 # inside hipGraph replays -- its counter passes crash on them), so the per-dispatch duration is the per-kernel number
 # that bench.py's `roofline` reports; the driver-shaped step counts are used as they are
 GATE=""; [ "$CFG" = c2 ] && GATE="--gate"     # short kernels: keep the traced dispatches back to back (bench.py --gate)
-CMD="python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --streams 1 --no-graph $GATE --steps 20 --warmup 5 --no-cpu-baseline --no-boundary"
+CMD="python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --streams 1 --no-graph $GATE --steps 20 --warmup 5 --no-cpu-baseline --no-boundary --no-parity"
 # counter passes: the same launches, fewer of them (the collector serialises every dispatch, and crashed on the 25 000
 # queued dispatches of the full-size command); counters are per-dispatch means, so the count does not matter
 PMC_CMD="$CMD --launches-per-step 32 --steps 10 --warmup 2"

@@ -8,7 +8,7 @@ TAG=${1:-r03}; CFG=${2:-c2}; S=${3:-4}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_overlap_${TAG}_${CFG}
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --streams $S --no-graph --gate --steps 10 --warmup 2 --no-cpu-baseline --no-boundary"
+CMD="python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --streams $S --no-graph --gate --steps 10 --warmup 2 --no-cpu-baseline --no-boundary --no-parity"
 echo "$CMD" > $OUT/command.txt
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1 || { echo "trace pass failed"; tail -5 $OUT/stats.log; }
 grep -h '"metric"' $OUT/stats.log | head -1 > $OUT/bench_lines.jsonl
