@@ -442,6 +442,16 @@ __device__ __forceinline__ cf mix_combine2(cf acc, cf pw) {
 // columns of an iteration are parked in the (then idle) exchange regions, and after a workgroup barrier all waves write
 // ARGB image rows -- runs of TPB pixels (32 bytes for the eight-frame workgroups) per row.  Neither the dB column nor an index
 // column goes to memory: per C5 column 4096 B in + 8196 B out, the algorithmic bytes.
+// Progress marks of the display kernels (OUTK == 2), eight per FFT round: a wave lowers its issue priority as it advances (3, 2, 1, 0,
+// cyclically), so of the two waves that share a SIMD the one that is BEHIND is served first.  Without them the arbiter prefers the older
+// wave for the whole iteration, and that wave then idles at the workgroup barrier of the store phase (in-kernel stamps, tools/abbench
+// AB_IMGSTAMPS: the median wave waited there for 20 % of a one-image launch, 7 % with the marks; C5 image in order 21.4 vs 22.0 us,
+// 30 000 columns in one launch 226 vs 235 us; the strided batches of the bench are level, 14.3 us per image either way).
+#ifndef JSG_X_NOMARKS
+#define JSG_MARK(k) do { if constexpr (OUTK == 2) __builtin_amdgcn_s_setprio(3 - ((k) & 3)); } while (0)
+#else
+#define JSG_MARK(k) do { } while (0)
+#endif
 template <class C, int MIXOP, int OUTK = 0>
 __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_kernel(
     // Everything the table and frame loads depend on sits in the first 16 dwords of the kernel arguments: with
@@ -637,6 +647,9 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         accNy[f] = init;
     }
 
+#ifdef JSG_X_IMGSTAMP   // development: cycle sums of the display epilogue's phases per wave (tools/abbench, AB_IMGSTAMPS=1)
+    unsigned long long ts_idx = 0, ts_bar1 = 0, ts_rd = 0, ts_st = 0, ts_n = 0, ts_k0 = __builtin_readcyclecounter(), ts_fft = 0, ts_last = 0;
+#endif
     // One FFT round of the sequence (F frames of one channel): consumes `raw` (loaded one round ago), re-issues it for
     // round s+1, transforms, accumulates |X|^2 into acc, and after the last channel of a column runs the mix epilogue + ring
     // store.  `last_tag` (std::true_type): the peeled final round of the wave, which prefetches nothing.  Peeling keeps
@@ -652,6 +665,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
 #pragma unroll
                 for (int m = 0; m < P; ++m) { raw[f][m].x = __int_as_float(0x3f800000 + lane + m + s + f); raw[f][m].y = 0.5f; }
         }
+        JSG_MARK(0);
         // ---- window multiply ----
 #pragma unroll
         for (int m = 0; m < P; m += 2) {
@@ -684,9 +698,11 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
             }
         }
         if constexpr (C::ABL != 1) {
+        JSG_MARK(1);
         // ---- stage 1: radix-R1 over n1, twiddle W_{R1R2}^{n2 k1}, exchange 1 ----
 #pragma unroll
         for (int u = 0; u < U1; ++u) {
+            if (u == U1 / 2) JSG_MARK(2);
             cf t[F][R1];
 #pragma unroll
             for (int f = 0; f < F; ++f) {
@@ -705,6 +721,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                 }
             }
         }
+        JSG_MARK(3);
         frame_sync();
 #pragma unroll
         for (int f = 0; f < F; ++f)
@@ -723,6 +740,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                 }
             }
         frame_sync();
+        JSG_MARK(4);
         // ---- stage 2: radix-R2 over n2, twiddle W_M^{n3 (k1 + R1 k2)}, exchange 2 ----
 #pragma unroll
         for (int v = 0; v < U2; ++v) {
@@ -757,6 +775,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         }
         if constexpr (!TWO) {
         frame_sync();
+        JSG_MARK(5);
         // ---- stage 3: radix-R3 over n3; Z[k], k = t3 + R1 R2 k3 ----
 #pragma unroll
         for (int f = 0; f < F; ++f)
@@ -782,6 +801,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                     for (int n3 = 0; n3 < R3; ++n3) x[f][w * R3 + n3] = lds0[f * C::LDS_ELEMS + e2r[w] + n3 * C::AZ];
                 }
             }
+        JSG_MARK(6);
         frame_sync();
 #pragma unroll
         for (int f = 0; f < F; ++f)
@@ -798,6 +818,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
             frame_sync();   // the post pass reuses the exchange buffer: keep its stores behind the exchange-1 loads
         }
         {
+            JSG_MARK(7);
             // ---- paired real-split post pass.  Bin k = ll + L*rho (rho = w + U3*k3).  A lane owns the pairs of its
             // lower registers rho < P/2: (k, M-k); Z[M-k] is the upper register P-1-rho of lane L-ll (lane 0: its own
             // register P-rho, and Z[M] = Z[0]).  With the window pre-scaled by 1/2 and T = (-i W_N^k) (Z[k] - conj Z[M-k]):
@@ -919,6 +940,11 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                     constexpr int D = C::LDS_ELEMS * 2;                       // dwords between the waves' regions
                     constexpr int SK = ((4 - D % 32) + 32) % 32;              // skew per wave: (D + SK) == 4 (mod 32)
                     unsigned* ix = reinterpret_cast<unsigned*>(lds0 + f * C::LDS_ELEMS) + (SK * wave) % 32;
+#ifdef JSG_X_IMGSTAMP
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const unsigned long long T0 = __builtin_readcyclecounter();
+                    if (ts_last) ts_fft += T0 - ts_last;
+#endif
 #pragma unroll
                     for (int r4 = 0; r4 < P / 8; ++r4) {
                         unsigned wx = 0, wy = 0;
@@ -933,7 +959,14 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                         ix[(P / 8 + r4) * 64 + ll] = wy;
                     }
                     if (ll == 0) ix[(P / 4) * 64] = (unsigned)color_index(accNy[f], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
+#ifdef JSG_X_IMGSTAMP
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const unsigned long long T1 = __builtin_readcyclecounter();
+#endif
                     __syncthreads();
+#ifdef JSG_X_IMGSTAMP
+                    const unsigned long long T2 = __builtin_readcyclecounter();
+#endif
                     {
                         // ---- store phase: every wave-instruction covers 8 consecutive values of ll (rows) x the 8 columns of the
                         //      iteration: lane = 8 * dl + c reads dword (hr, 8 wave + dl) of column c and writes four pixels.  Wave w takes the
@@ -961,6 +994,9 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                         // (Also tried: the waves 0-3 deferring their pixels into the middle of their next FFT round so that on every SIMD one
                         // wave's stores lie under the other's arithmetic: 229 vs 221 us)
                         __syncthreads();
+#ifdef JSG_X_IMGSTAMP
+                        const unsigned long long T3 = __builtin_readcyclecounter();
+#endif
                         unsigned x = (unsigned)a.x_first + tcol;                      // x_first < x_wrap, tcol < n_frames <= x_wrap (launcher)
                         if (x >= (unsigned)a.x_wrap) x -= (unsigned)a.x_wrap;
                         const unsigned pitch4 = (unsigned)a.argb_pitch * 4u, step = 64u * pitch4;
@@ -986,6 +1022,11 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                                 *reinterpret_cast<unsigned*>(img + ((unsigned)(M / 2) * pitch4 + x * 4u)) = rgb;
                             }
                         }
+#ifdef JSG_X_IMGSTAMP
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        const unsigned long long T4 = __builtin_readcyclecounter();
+                        ts_idx += T1 - T0; ts_bar1 += T2 - T1; ts_rd += T3 - T2; ts_st += T4 - T3; ts_n += 1; ts_last = T4;
+#endif
                     }
                 } else if constexpr (OUTK == 1) {
                     // palette index of every bin; 64 consecutive bytes of the index column per store instruction
@@ -1027,6 +1068,14 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
 
     for (int s = 0; s + 1 < n_fft; ++s) process(s, std::false_type{});
     process(n_fft - 1, std::true_type{});
+#ifdef JSG_X_IMGSTAMP
+    if constexpr (OUTK == 2) {
+        if (lane == 0 && a.stamps) {
+            unsigned long long* d = a.stamps + (size_t)(blockIdx.x * C::WPB + wave) * 10;
+            d[0] = ts_idx; d[1] = ts_bar1; d[2] = ts_rd; d[3] = ts_st; d[4] = ts_n; d[5] = __builtin_readcyclecounter() - ts_k0; d[6] = ts_fft;
+        }
+    }
+#endif
     if constexpr (C::ABL == 3) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long st3 = __builtin_readcyclecounter();

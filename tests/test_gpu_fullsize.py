@@ -304,6 +304,47 @@ def test_seeded_random_fused_images(jsg, oracle, torch_cuda, n, channels, mix, f
     assert torch.equal(fused, two)
 
 
+def _random_batches(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        n = int(rng.choice([512, 1024, 1024, 2048, 4096, 4096]))
+        channels = int(rng.integers(1, 5))
+        mix = int(rng.choice([0, 0, 3, 4]))
+        if mix == 4 and channels < 2:
+            mix = 3
+        fb = int(rng.choice([2, 4, 8]))
+        frames = int(rng.integers(1, 120))
+        wimg = frames + int(rng.choice([0, 0, 1, 5, 32]))
+        x_first = int(rng.integers(0, wimg))
+        sel = int(rng.choice([1, 2])) if n in (2048, 4096) else 0          # pinned: the batch and the single launches take the same plan
+        out.append((n, channels, mix, fb, frames, wimg, x_first, int(rng.integers(2, 10)), int(rng.integers(0, 3)), sel))
+    return out
+
+
+@pytest.mark.parametrize("n,channels,mix,fb,frames,wimg,x_first,K,gap,sel",
+                         _random_batches(max(8, int(os.environ.get("JSG_FUZZ_CASES", "24")) // 2), int(os.environ.get("JSG_FUZZ_SEED", "5")) + 77))
+def test_seeded_random_strided_batches(jsg, oracle, torch_cuda, n, channels, mix, fb, frames, wimg, x_first, K, gap, sel):
+    """jsg_stft_image_launch_strided against K single launches over plans (one-kernel and two-kernel forms) / channel counts / mixes /
+    ragged widths / wraps in x / rows of padding between the images: the same pixels, nothing else touched."""
+    torch = torch_cuda
+    hop = n // fb
+    H = n // 2 + 1
+    plan = jsg.Plan(n, oracle.window(oracle.WIN_HANN, n))
+    d_in = torch.stack([_stream(torch, channels, (frames - 1) * hop + n, seed=n + frames + 31 * k) for k in range(K)]).contiguous()
+    d_lut = torch.from_numpy(jsg.colormap_lut(256, jsg.capi.CM_JADE)).cuda()
+    ref = torch.full((K, H + gap, wimg), 0x0badf00d, dtype=torch.int32, device="cuda")
+    out = torch.full((K, H + gap, wimg), 0x0badf00d, dtype=torch.int32, device="cuda")
+    scratch = torch.zeros((frames, (H + 63) // 64 * 64), dtype=torch.uint8, device="cuda")
+    kw = dict(feedblocks=fb, mix_mode=mix, ring_width=frames, x_first=x_first, plan_select=sel)
+    for k in range(K):
+        jsg.stft_image(plan, d_in[k], hop, frames, d_lut, -70.0, 30.0, ref[k, :H], scratch, **kw)
+    jsg.stft_image_strided(plan, d_in, hop, frames, d_lut, -70.0, 30.0, out[:, :H], scratch, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert int((out == 0x0badf00d).sum()) == K * (H * (wimg - frames) + gap * wimg)
+
+
 def _b_rule(frames, frames_per_workgroup, n_cu, fill=0.87):
     """The launcher's rule for the "B" kernels (csrc/jsg_kernels.hip: b_plan_fills_its_rounds)."""
     want = -(-frames // frames_per_workgroup)
@@ -514,6 +555,10 @@ def test_one_kernel_image_alignments_wraps_and_ragged_widths(jsg, oracle, torch_
     (1024, 2, 999, 1000, 3, 9, 0),
     (1024, 2, 8, 8, 0, 33, 0),           # one group per image
     (1024, 1, 5, 8, 6, 3, 0),            # less than a group per image, wrapping
+    (4096, 2, 1875, 1888, 0, 9, 0),      # several rounds of groups per workgroup
+    (4096, 1, 301, 320, 20, 56, 2),      # many small images, wrap in x inside the images
+    (4096, 2, 1875, 1888, 7, 9, 0),      # odd x_first
+    (4096, 2, 1874, 1876, 2, 9, 0),      # image width that is not a multiple of 8
 ])
 def test_strided_image_batch_equals_single_launches(jsg, oracle, torch_cuda, n, C, F, Wimg, x_first, K, sel):
     """jsg_stft_image_launch_strided: K images of one geometry in ONE kernel launch (the workgroups walk through the columns of all

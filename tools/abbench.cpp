@@ -521,6 +521,41 @@ int main(int argc, char** argv) {
                 }
             }
         }
+        if (std::getenv("AB_IMGSTAMPS") && c.colour) {
+            // builds with -DJSG_DEV_VARIANTS -DJSG_X_IMGSTAMP: per-wave cycle sums of the phases of the one-kernel display path
+            for (size_t li = 0; li < libs.size(); ++li) {
+                Lib& l = libs[li];
+                if (!l.set_stamps || !l.stft_image) continue;
+                const size_t nw = 256 * 8;
+                unsigned long long* d_st = nullptr;
+                CK(hipMalloc(reinterpret_cast<void**>(&d_st), nw * 10 * 8));
+                CK(hipMemset(d_st, 0, nw * 10 * 8));
+                for (int rep = 0; rep < 3; ++rep) {
+                    if (rep == 2) l.set_stamps(d_st);
+                    jsg_stft_image_args fa{};
+                    fa.stft = args_for(rep % nbuf);
+                    fa.stft.out_db = nullptr;
+                    fa.colour = ca;
+                    fa.colour.db = nullptr;
+                    fa.colour.argb_out = d_img[rep % nbuf];
+                    l.stft_image(plans[li], &fa, one);
+                    CK(hipStreamSynchronize(one));
+                }
+                l.set_stamps(nullptr);
+                std::vector<unsigned long long> st(nw * 10);
+                CK(hipMemcpy(st.data(), d_st, nw * 10 * 8, hipMemcpyDeviceToHost));
+                CK(hipFree(d_st));
+                const char* nm[7] = {"colour index + LDS writes", "wait at barrier 1", "index reads + barrier 2", "palette reads + stores issued", "epilogues", "kernel (cycles)", "between epilogues (FFT rounds)"};
+                std::printf("   image stamps %s (cycles per wave, summed over its epilogues; median / p90 over waves)\n", l.path.c_str());
+                for (int k = 0; k < 7; ++k) {
+                    std::vector<double> v;
+                    for (size_t w = 0; w < nw; ++w) if (st[w * 10 + 4]) v.push_back(double(st[w * 10 + k]));
+                    if (v.empty()) continue;
+                    std::sort(v.begin(), v.end());
+                    std::printf("      %-32s median %10.0f  p90 %10.0f  (waves %zu)\n", nm[k], v[v.size() / 2], v[size_t(0.9 * double(v.size() - 1))], v.size());
+                }
+            }
+        }
         auto time_inorder = [&](size_t li, int count, bool fused) {
             Lib& l = libs[li];
             for (int i = 0; i < count; ++i) {
