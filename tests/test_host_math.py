@@ -87,6 +87,8 @@ def test_bad_arguments_are_rejected(jsg):
     ia = cap.StftImageArgs()
     assert lib.jsg_stft_image_needs_scratch(None, C.byref(ia)) == cap.JSG_ERR_INVALID
     assert lib.jsg_stft_image_launch(None, C.byref(ia), None) == cap.JSG_ERR_INVALID
+    assert lib.jsg_stft_image_strided_needs_scratch(None, C.byref(ia), 2) == cap.JSG_ERR_INVALID
+    assert lib.jsg_stft_image_launch_strided(None, C.byref(ia), 2, 0, 0, None) == cap.JSG_ERR_INVALID
     msg = lib.jsg_last_error(None)
     assert msg and b"null" in msg
 
