@@ -639,6 +639,15 @@ def test_strided_image_batch_fallback_and_error_paths(jsg, oracle, torch_cuda):
     assert call(K, d_in.stride(0), out.stride(0)) == cap.JSG_OK
     torch.cuda.synchronize()
     assert bool(out[K - 1].any())
+    # more groups than one launch addresses (2^20): refused before anything is launched (the buffers need not exist)
+    out.zero_()
+    assert call((1 << 20) // 8 + 1, d_in.stride(0), out.stride(0)) == cap.JSG_ERR_UNSUPPORTED
+    torch.cuda.synchronize()
+    assert not out.any()
+    # in_image_stride = 0: every image is computed from the same input
+    assert call(K, 0, out.stride(0)) == cap.JSG_OK
+    torch.cuda.synchronize()
+    assert bool(out[0].any()) and all(torch.equal(out[k], out[0]) for k in range(1, K))
 
 
 def test_image_launch_error_paths_return_codes(jsg, oracle, torch_cuda):
