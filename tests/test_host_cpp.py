@@ -168,6 +168,34 @@ def test_several_engines_from_one_host_process(jsg, shards):
     assert info["sharded_api_differing"] == 0      # jsg_create_sharded / jsg_process_block_sharded: the same shards, the same bits
 
 
+def _build_offline_render_example(jsg):
+    libdir = os.path.dirname(jsg.capi.LIB_PATH)
+    exe = os.path.join(tempfile.gettempdir(), "jsg_offline_render_example")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+                           "-isystem", "/opt/rocm/include", os.path.join(ROOT, "tests", "cpp", "offline_render_example.cpp"), "-o", exe,
+                           "-L", libdir, "-ljsg", f"-Wl,-rpath,{libdir}", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"])
+    return exe
+
+
+def test_offline_render_example_compiles_and_links(jsg):
+    """The C++ worked example of the strided image batches (offline rendering) builds against jsg.h as a C++ host
+    would use it: plain structs, device pointers, a stream handle."""
+    assert os.path.exists(_build_offline_render_example(jsg))
+
+
+@pytest.mark.gpu
+def test_offline_render_example_runs(jsg):
+    """Twelve stereo 96 kHz images (the C5 geometry) from ONE jsg_stft_image_launch_strided call equal twelve jsg_stft_image_launch
+    calls pixel for pixel (reference pixel loop: Spectrogram.cpp:632-648), the padding columns of the images stay untouched."""
+    exe = _build_offline_render_example(jsg)
+    r = subprocess.run([exe, "12", "1875"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    if "skipped" not in info:
+        assert info["pixels_differing"] == 0 and info["padding_pixels_touched"] == 0 and info["opaque_pixels"] == info["pixels"]
+        assert info["one_kernel_for_the_batch"] is True
+
+
 def _build_rccl_example(jsg):
     libdir = os.path.dirname(jsg.capi.LIB_PATH)
     exe = os.path.join(tempfile.gettempdir(), "jsg_rccl_absmean_example")
