@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define JSG_ABI_VERSION 4   /* 3: + kernel-name query, launch pool, image scratch query, sharded set; 4: + strided image batches (round 3) */
+#define JSG_ABI_VERSION 5   /* 3: + kernel-name query, launch pool, image scratch query, sharded set; 4: + strided image batches (round 3);
+                               5: + strided dB batches, exact-log mode, producer ring statistics (round 4) */
 
 typedef enum jsg_status {
     JSG_OK = 0,
@@ -143,7 +144,9 @@ typedef struct jsg_stft_args {
                                 kernel otherwise.  1: always the small-workgroup kernel, 2: always "B".  The two round differently in
                                 the last bits (both inside the parity bound): callers that cut one stream into launches of
                                 very different sizes and need bit-identical columns pin one of them (the engine pins 1).
-                                jsg_stft_kernel_name() tells which one a launch takes.  Other sizes: ignored */
+                                jsg_stft_kernel_name() tells which one a launch takes.  1024 points, jsg_stft_db_launch_strided only:
+                                1 = never the staged form, 2 = the staged form wherever the geometry allows it (automatic: from four
+                                steps of sixteen frames per CU on).  Other sizes: ignored */
     int32_t reserved;        /* 0 */
 } jsg_stft_args;
 int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* args, void* stream);
@@ -179,6 +182,27 @@ int jsg_stft_db_launch_many_threads(const jsg_plan* plan, const jsg_stft_args* a
  * other streams busy at the same time shares the four slots with them.  Calls for one device are serialised on the host.
  * Inside a stream capture (hipGraph) the launches are issued by the calling thread and become parallel branches of the graph. */
 int jsg_stft_db_launch_batches(const jsg_plan* plan, const jsg_stft_args* args, int count, void* stream);
+
+/* `n_batches` independent batches of ONE geometry in ONE kernel launch on ONE stream (the frame loop of
+ * Spectrogram::processSynchronBlock, Spectrogram.cpp:50-119, over K streams' worth of blocks): `args` describes batch 0; batch b reads
+ * args->in + b * in_batch_stride (floats; 0 = the same input) and writes its own ring at args->out_db + b * out_batch_stride (floats,
+ * at least one ring: the rings must not overlap).  Everything else in `args` (frame count, hop, ring_pos, mix, in_samples -- which then
+ * holds for the rows of EVERY batch) is the same for all batches.  The workgroups of the one launch walk through the columns of all
+ * batches: lane tables loaded once per workgroup instead of once per eight frames, no ramp-up and drain per batch, the next columns in
+ * flight while the current ones are transformed -- the rate of back-to-back launches without extra streams, hardware queues or issuing
+ * threads (bench.py's default C2 step).
+ *   1024 points, regular hop <= 512 that is a multiple of four samples, 16-byte aligned rows and strides, >= 16 frames per batch,
+ *   AbsMean / Sum / Left / Right / per-channel: the STAGED form -- one persistent 16-wave workgroup per CU; the contiguous input span of
+ *   sixteen frames is brought into LDS once by LDS-DMA (every sample leaves HBM and the L2 once, 1 KB per wave-instruction) one step
+ *   ahead, and the waves read their frames from LDS.  Same radices, tables and operation order as jsg_stft_db_launch: bit-identical columns.
+ *   Everything else: the plan's usual kernel walking through all batches (2048 / 4096 points: the plan rule of plan_select looks at
+ *   the frames of the WHOLE launch; columns are those of single launches with plan_select pinned to that plan).
+ * Max / Min mixes have no strided kernel: they are launched batch by batch in stream order.  More than 2^20 workgroup steps go out as
+ * several launches.  jsg_stft_db_strided_kernel_name tells the kernel ("Cfg1024S" = staged). */
+int jsg_stft_db_launch_strided(const jsg_plan* plan, const jsg_stft_args* args, int n_batches, int64_t in_batch_stride,
+                               int64_t out_batch_stride, void* stream);
+int jsg_stft_db_strided_kernel_name(const jsg_plan* plan, const jsg_stft_args* args, int n_batches, int64_t in_batch_stride, char* out,
+                                    int out_len);
 
 /* out[i] = 10*log10(power[i]/divisor + 1e-11f), i < count: the tail of the mix (reference Spectrogram.cpp:74,107)
  * for partial sums that were reduced across GPUs (JSG_MIX_SUM).  In place (out == power) is allowed. */

@@ -45,14 +45,10 @@
 
 #include "jsg_internal.h"
 
-// Hardware queues (jsg.h, jsg_stft_db_launch_batches): the HIP runtime reads GPU_MAX_HW_QUEUES at its first API call and maps the
-// streams of the process onto that many hardware queues (default 4) in creation order.  Unless the user chose a value (or
-// JSG_KEEP_HW_QUEUES is set), give the process sixteen, so that the four working streams of the launch pool, the engine's two and the
-// host's own each get a queue: two BUSY streams on one queue serialise (measured: 0.41-0.84e9 instead of 1.08e9 frames/s at C2).
-__attribute__((constructor)) static void jsg_default_hw_queues() {
-    if (!getenv("JSG_KEEP_HW_QUEUES")) (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
-}
-
+// (Rounds 2-3 had a library constructor here that set GPU_MAX_HW_QUEUES for the process.  It is gone: a plugin is loaded into a
+// multi-threaded host, setenv is not thread-safe there, and the variable changes every other HIP user of the process.  The
+// multi-stream launch pool -- jsg_stft_db_launch_batches -- documents the variable in INTEGRATION.md instead, and the headline path
+// no longer needs it: jsg_stft_db_launch_strided is one launch on one stream.)
 namespace jsg {
 
 std::string& tls_error() {

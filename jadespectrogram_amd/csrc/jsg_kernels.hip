@@ -270,7 +270,7 @@ int jsg_plan_create(jsg_plan** out, int n, const float* window, float power_scal
     hipError_t err = hipSuccess;
     switch (n) {
         case 512: err = ensure_attrs_Cfg512(); break;
-        case 1024: err = ensure_attrs_Cfg1024(); break;
+        case 1024: err = ensure_attrs_Cfg1024(); if (err == hipSuccess) err = ensure_attrs_Cfg1024S(); break;
         case 2048: err = ensure_attrs_Cfg2048(); if (err == hipSuccess) err = ensure_attrs_Cfg2048B(); break;
         case 4096: err = ensure_attrs_Cfg4096(); if (err == hipSuccess) err = ensure_attrs_Cfg4096B(); break;
         case 8192: err = ensure_attrs_Cfg8192(); break;
@@ -326,7 +326,33 @@ static bool wants_plan_b(int n, const jsg_stft_args* g, int nc, int n_cu, long l
                            b_plan_fills_its_rounds(frames_of_launch >= 0 ? frames_of_launch : g->n_frames, tpb_b, n_cu));
 }
 
-static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const IndexOut* io, void* stream) {
+namespace {
+struct BatchSpec {   // jsg_stft_db_launch_strided: `n` batches of the geometry in jsg_stft_args, batch b at in + b * in_stride, out_db + b * out_stride
+    int n;
+    long long in_stride, out_stride;
+    int mode;        // 1: STREAM == 1 (frame-by-frame loads), 2: STREAM == 2 (staged spans, Cfg1024S) -- chosen by strided_mode()
+};
+}  // namespace
+
+// Which form a strided launch of `n_batches` batches takes: 2 = the staged 1024-point kernel (one persistent 16-wave workgroup per CU,
+// input spans through LDS), 1 = the plan's usual kernel walking through all batches.  The staged form needs a regular hop <= n / 2 that
+// is a multiple of four samples, 16-byte aligned rows, rows of at least sixteen frames, a sum-type or one-channel mix, and enough work to
+// give every CU several steps (>= 4 steps of sixteen frames per CU); everything else takes form 1.  jsg_stft_args.plan_select = 1 | 2
+// pins form 1 / the staged form wherever the geometry allows it (JSG_STRIDED_MODE=1|2: the same from the environment, development A/B).
+static int strided_mode(const jsg_plan* plan, const jsg_stft_args* g, int n_batches, long long in_stride, int n_cu) {
+    static const int forced = [] { const char* e = getenv("JSG_STRIDED_MODE"); return e ? atoi(e) : 0; }();
+    if (plan->n != 1024 || forced == 1 || g->plan_select == 1) return 1;
+    const bool geometry = (long long)g->hop * g->feedblocks == plan->n && g->hop <= plan->n / 2 && g->hop % 4 == 0 && g->n_frames >= Cfg1024S::TPB &&
+                          ((reinterpret_cast<unsigned long long>(g->in) | (unsigned long long)(g->in_pitch * 4) | (unsigned long long)(in_stride * 4) |
+                            (unsigned long long)(g->first_frame * g->hop * 4)) & 15ull) == 0 &&
+                          g->mix_mode != JSG_MIX_MAX && g->mix_mode != JSG_MIX_MIN;
+    if (!geometry) return 1;
+    const long long rows = (long long)n_batches * (g->mix_mode == JSG_MIX_PER_CHANNEL ? g->channels : 1);
+    const long long steps = rows * ((g->n_frames + Cfg1024S::TPB - 1) / Cfg1024S::TPB);
+    return (forced == 2 || g->plan_select == 2 || steps >= 4ll * n_cu) ? 2 : 1;
+}
+
+static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const IndexOut* io, void* stream, const BatchSpec* bs = nullptr) {
     if (!plan || !g) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: null argument");
     if (g->n_frames == 0) return JSG_OK;
     const int H = plan->n / 2 + 1;
@@ -429,12 +455,16 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     // geometry (channels per column, frames, CU count) only; sub-launches of one stream that fall on different sides of the rule
     // agree within the float32 bound, not bit for bit (jsg.h: plan_select pins one plan).
     // (the single-kernel display path exists for the one-wavefront-per-frame plans: at 4096 points that is "B")
-    const bool plan_b = (io && io->argb && plan->n == 4096) || wants_plan_b(plan->n, g, ka.per_channel ? 1 : ka.c_end - ka.c_begin, n_cu);
+    const bool staged = bs && bs->mode == 2;   // (1024 points: Cfg1024S shares Cfg1024's tables)
+    const long long rows = bs ? (long long)bs->n * (ka.per_channel ? g->channels : 1) : 1;
+    // (a strided launch is judged by the frames of ALL its rows: the "B" kernels then fill their rounds)
+    const bool plan_b = (io && io->argb && plan->n == 4096) ||
+                        wants_plan_b(plan->n, g, ka.per_channel ? 1 : ka.c_end - ka.c_begin, n_cu, bs ? rows * g->n_frames : -1);
     if (plan_b) ka.tab = plan->d_tab_b;
     int tpb = 0;
     switch (plan->n) {
         case 512: tpb = Cfg512::TPB; break;
-        case 1024: tpb = Cfg1024::TPB; break;
+        case 1024: tpb = staged ? Cfg1024S::TPB : Cfg1024::TPB; break;
         case 2048: tpb = plan_b ? Cfg2048B::TPB : Cfg2048::TPB; break;
         case 4096: tpb = plan_b ? Cfg4096B::TPB : Cfg4096::TPB; break;
         case 8192: tpb = Cfg8192::TPB; break;
@@ -449,7 +479,21 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
         ka.n_groups = unsigned(want);
         ka.img_magic = ((1ull << 40) + (unsigned long long)gpi - 1) / (unsigned long long)gpi;
     }
-    const int ny = ka.per_channel ? g->channels : 1;
+    if (bs) {   // strided multi-batch launch: the groups are numbered through the rows (batches, or batch x channel)
+        const long long gpr = want;
+        want = gpr * rows;
+        if (gpr > (1ll << 20) || want > (1ll << 20))
+            return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_db_launch_strided: more than 2^20 workgroup steps in one launch");
+        ka.img_gpi = unsigned(gpr);
+        ka.n_groups = unsigned(want);
+        ka.img_magic = ((1ull << 40) + (unsigned long long)gpr - 1) / (unsigned long long)gpr;
+        ka.bat_cpb = ka.per_channel ? unsigned(g->channels) : 1u;
+        ka.bat_magic = ((1ull << 40) + (unsigned long long)ka.bat_cpb - 1) / (unsigned long long)ka.bat_cpb;
+        ka.in_image_stride = bs->in_stride;
+        ka.out_batch_stride = bs->out_stride;
+        ka.span_bytes = unsigned(((long long)(tpb - 1) * g->hop + plan->n) * 4);
+    }
+    const int ny = (ka.per_channel && !bs) ? g->channels : 1;
     if (ny > 65535) return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_db_launch: more than 65535 channels in per-channel mode");
     static const int blocks_per_cu_env = [] {   // tuning knob (development): JSG_STFT_BLOCKS_PER_CU
         const char* e = getenv("JSG_STFT_BLOCKS_PER_CU");
@@ -459,7 +503,7 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     // workgroups per CU of the grid; the rest of the frames is looped over.  The "B" plans hold one workgroup per CU: a grid of
     // exactly that many keeps the tables and the prefetch pipeline alive across a workgroup's frames (16 384 mono 4096-point
     // frames: 65 vs 79 us with a grid of 8 per CU); the other plans do best with more workgroups than are resident.
-    const int bpc = g->blocks_per_cu > 0 ? g->blocks_per_cu : (blocks_per_cu_env > 0 ? blocks_per_cu_env : (plan_b ? 1 : 8));
+    const int bpc = staged ? 1 : g->blocks_per_cu > 0 ? g->blocks_per_cu : (blocks_per_cu_env > 0 ? blocks_per_cu_env : (plan_b ? 1 : 8));
     long long max_blocks = (long long)n_cu * bpc / ny;     // resident workgroups; the rest is looped over
     if (max_blocks < 64) max_blocks = 64;
     static const int max_blocks_env = [] { const char* e = getenv("JSG_STFT_MAX_BLOCKS"); return e ? atoi(e) : 0; }();   // development
@@ -469,6 +513,17 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     const dim3 grid(nblk, ny);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipError_t err = hipSuccess;
+    if (bs) {
+        switch (plan->n) {
+            case 512: err = launch_strided_Cfg512(ka, mixop, grid, s); break;
+            case 1024: err = staged ? launch_strided_Cfg1024S(ka, mixop, grid, s) : launch_strided_Cfg1024(ka, mixop, grid, s); break;
+            case 2048: err = plan_b ? launch_strided_Cfg2048B(ka, mixop, grid, s) : launch_strided_Cfg2048(ka, mixop, grid, s); break;
+            case 4096: err = plan_b ? launch_strided_Cfg4096B(ka, mixop, grid, s) : launch_strided_Cfg4096(ka, mixop, grid, s); break;
+            case 8192: err = launch_strided_Cfg8192(ka, mixop, grid, s); break;
+        }
+        if (err != hipSuccess) return jsg_fail_hip(err, "jsg_stft_db_launch_strided");
+        return JSG_OK;
+    }
     switch (plan->n) {
         case 512: err = launch_Cfg512(ka, mixop, grid, s); break;
         case 1024: err = launch_Cfg1024(ka, mixop, grid, s); break;
@@ -595,6 +650,75 @@ int jsg_stft_image_launch_strided(const jsg_plan* plan, const jsg_stft_image_arg
         const int rc = jsg_stft_image_launch(plan, &one, stream);
         if (rc != JSG_OK) return rc;
     }
+    return JSG_OK;
+}
+
+// K independent batches of ONE geometry in ONE kernel launch on ONE stream (reference loop: Spectrogram.cpp:50-119 over K streams'
+// worth of blocks): batch b reads args->in + b * in_batch_stride and writes its own ring at args->out_db + b * out_batch_stride.
+// The workgroups of the launch walk through the columns of all batches: tables loaded once per workgroup, no ramp-up and drain per
+// batch, no dependence on extra streams, hardware queues or issuing threads.
+static int strided_checks(const jsg_plan* plan, const jsg_stft_args* g, int n_batches, int64_t in_batch_stride, int64_t out_batch_stride, const char* who) {
+    if (!plan || !g) return jsg_fail(JSG_ERR_INVALID, (std::string(who) + ": null argument").c_str());
+    if (n_batches < 0) return jsg_fail(JSG_ERR_INVALID, (std::string(who) + ": negative batch count").c_str());
+    if (in_batch_stride < 0 || out_batch_stride < 0) return jsg_fail(JSG_ERR_INVALID, (std::string(who) + ": negative stride").c_str());
+    if (n_batches > 1 && g->n_frames > 0) {
+        if (g->channels <= 0 || g->ring_width <= 0 || g->out_pitch <= 0) return jsg_fail(JSG_ERR_INVALID, (std::string(who) + ": bad geometry").c_str());
+        const long long ring_extent = (g->mix_mode == JSG_MIX_PER_CHANNEL ? (long long)(g->channels - 1) * g->out_channel_pitch : 0ll) +
+                                      (long long)(g->ring_width - 1) * g->out_pitch + plan->n / 2 + 1;
+        if (out_batch_stride < ring_extent)
+            return jsg_fail(JSG_ERR_INVALID, (std::string(who) + ": the rings of consecutive batches would overlap (out_batch_stride too small)").c_str());
+        // the caller told us how long the channel rows are: consecutive batches may share samples (stride < row length: a long stream
+        // cut along time), but a batch must not reach past what the stride + in_samples describe for the LAST batch -- checked per
+        // batch by the launcher -- and a stride of 0 means "the same input for every batch"
+        if (g->in_samples != 0 && in_batch_stride != 0 && g->channels > 1 && g->in_pitch < g->in_samples)
+            return jsg_fail(JSG_ERR_INVALID, (std::string(who) + ": in_pitch < in_samples").c_str());
+    }
+    return JSG_OK;
+}
+
+int jsg_stft_db_launch_strided(const jsg_plan* plan, const jsg_stft_args* g, int n_batches, int64_t in_batch_stride, int64_t out_batch_stride,
+                               void* stream) {
+    int rc = strided_checks(plan, g, n_batches, in_batch_stride, out_batch_stride, "jsg_stft_db_launch_strided");
+    if (rc != JSG_OK) return rc;
+    if (n_batches == 0 || g->n_frames == 0) return JSG_OK;
+    if (n_batches == 1) return jsg_stft_db_launch(plan, g, stream);
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return jsg_fail(JSG_ERR_NO_DEVICE, "jsg_stft_db_launch_strided: no device");
+    const bool one_by_one = g->mix_mode == JSG_MIX_MAX || g->mix_mode == JSG_MIX_MIN;   // (no strided instantiation: rare modes)
+    if (g->n_frames < 0 || g->channels <= 0) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch_strided: bad geometry");
+    const long long rows_per_batch = g->mix_mode == JSG_MIX_PER_CHANNEL ? g->channels : 1;
+    // at most 2^20 workgroup steps per launch (the kernel's group -> row arithmetic): longer jobs go out in several launches
+    const long long steps_per_batch = rows_per_batch * ((g->n_frames + 7) / 8);
+    const long long per_launch = one_by_one ? 1 : std::max(1ll, (1ll << 20) / std::max(1ll, steps_per_batch));
+    for (long long b0 = 0; b0 < n_batches; b0 += per_launch) {
+        const int nb = int(std::min<long long>(per_launch, n_batches - b0));
+        jsg_stft_args one = *g;
+        one.in = g->in + b0 * in_batch_stride;
+        one.out_db = g->out_db ? g->out_db + b0 * out_batch_stride : nullptr;
+        if (nb == 1) rc = jsg_stft_db_launch(plan, &one, stream);
+        else {
+            BatchSpec bs{nb, (long long)in_batch_stride, (long long)out_batch_stride, 1};
+            bs.mode = strided_mode(plan, &one, nb, in_batch_stride, cu_count_of_device(dev));
+            rc = stft_launch_impl(plan, &one, nullptr, stream, &bs);
+        }
+        if (rc != JSG_OK) return rc;
+    }
+    return JSG_OK;
+}
+
+// The kernel a strided launch takes, as text ("Cfg1024S" = the staged persistent form, else as jsg_stft_kernel_name for the total size).
+int jsg_stft_db_strided_kernel_name(const jsg_plan* plan, const jsg_stft_args* g, int n_batches, int64_t in_batch_stride, char* out, int out_len) {
+    if (!plan || !g || !out || out_len < 24 || n_batches < 1) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_strided_kernel_name: bad argument");
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return jsg_fail(JSG_ERR_NO_DEVICE, "jsg_stft_db_strided_kernel_name: no device");
+    if (n_batches == 1) return jsg_stft_kernel_name(plan, g, out, out_len);
+    const int n_cu = cu_count_of_device(dev);
+    if (strided_mode(plan, g, n_batches, in_batch_stride, n_cu) == 2) { std::snprintf(out, size_t(out_len), "Cfg1024S"); return JSG_OK; }
+    int nc = g->channels;
+    if (g->mix_mode == JSG_MIX_LEFT || g->mix_mode == JSG_MIX_RIGHT || g->mix_mode == JSG_MIX_PER_CHANNEL) nc = 1;
+    const long long rows = (long long)n_batches * (g->mix_mode == JSG_MIX_PER_CHANNEL ? g->channels : 1);
+    const bool b = wants_plan_b(plan->n, g, nc, n_cu, rows * g->n_frames);
+    std::snprintf(out, size_t(out_len), "Cfg%d%s", plan->n, b ? "B" : "");
     return JSG_OK;
 }
 

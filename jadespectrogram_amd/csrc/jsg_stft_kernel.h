@@ -24,6 +24,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdint>
@@ -278,6 +279,10 @@ using Cfg512 = Cfg<512, 8, 8, 4, 32, 36, 4, 33, 1, 8, 1, 2>;   // (a 80-VGPR bud
 #define JSG_X_WPS1024 6   // Left at 2 the ILP-first scheduler takes 88 for the mixing instantiations (two workgroups per CU): stereo -2..-4 % with the cap
 #endif
 using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, JSG_X_WPB1024, 1, JSG_X_WPS1024, JSG_X_FPW1024, JSG_X_ABL>;
+// The 1024-point plan as ONE persistent 16-wave workgroup per CU for the strided multi-batch launch (stft_db_kernel, STREAM == 2): the
+// same radices, layouts and tables as Cfg1024 (bit-identical results), sixteen frames per step.  16 x 4.5 KB of exchange + 10.7 KB of
+// tables leave room for two input spans of 34 KB (sixteen frames of hop 512), see STREAM below.  Four waves per SIMD: <= 128 VGPRs.
+using Cfg1024S = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 16, 1, 4>;
 #ifndef JSG_X_TWF2048      // factorised stage-2 / post tables (Cfg::TWF): 11.3 instead of 21.2 KB of tables, so that THREE 4-wave
 #define JSG_X_TWF2048 1    // workgroups fit a CU (12 waves instead of 8): stereo launches -9..-13 %, mono -1..-5 %
 #endif
@@ -368,6 +373,13 @@ struct StftKArgs {
     unsigned long long img_magic; // ceil(2^40 / img_gpi): group / img_gpi == (group * img_magic) >> 40 exactly for group, img_gpi <= 2^20
     long long in_image_stride;    // floats between the inputs of consecutive images
     long long argb_image_stride;  // pixels between consecutive images
+    // STREAM != 0 (jsg_stft_db_launch_strided): the same numbering through the ROWS of the launch -- a row is one batch, or one
+    // (batch, channel) pair in per-channel mode: row = batch * bat_cpb + channel.  n_groups / img_gpi / img_magic / in_image_stride
+    // (floats between the inputs of consecutive batches) are shared with the image form above.
+    unsigned bat_cpb;             // rows per batch: channels in per-channel mode, else 1
+    unsigned long long bat_magic; // ceil(2^40 / bat_cpb)
+    long long out_batch_stride;   // floats between the rings of consecutive batches
+    unsigned span_bytes;          // STREAM == 2: bytes of the input span of one step = ((TPB - 1) * hop + N) * 4
 };
 
 // dB = 10*log10(p + 1e-11f) -- reference Spectrogram.cpp:107 with g_minValForLogSpectrogram (:36).
@@ -452,7 +464,21 @@ __device__ __forceinline__ cf mix_combine2(cf acc, cf pw) {
 #else
 #define JSG_MARK(k) do { } while (0)
 #endif
-template <class C, int MIXOP, int OUTK = 0>
+// bytes of the largest input span of one step of the staged form (STREAM == 2): TPB frames at hop N / 2; a multiple of 1 KB
+template <class C>
+constexpr int stage_bytes = ((C::TPB - 1) * (C::N / 2) + C::N) * 4;
+
+// STREAM (jsg_stft_db_launch_strided: K independent batches of one geometry in ONE launch, OUTK == 0): 0 = one batch per launch;
+// 1 = the workgroups walk through the groups (TPB consecutive columns) of all batches, everything else as for one batch: tables loaded
+// once per workgroup and launch, the prefetch pipeline alive across batches, no ramp-up and drain per 4096 frames;
+// 2 = additionally the input is STAGED: the contiguous span of a step's TPB frames ((TPB - 1) hop + N samples: every sample once) is
+// brought into LDS by LDS-DMA -- 16 bytes per lane, 1 KB per wave-instruction, issued by all waves together right behind the step's
+// workgroup barrier, one step ahead, two buffers -- and the waves read their frames from LDS (the 50..87.5 % overlap is served there, no
+// VGPRs are spent on the prefetch).  Why: what HBM delivers depends on how tight the chip-wide access front is; the frame-by-frame
+// loads of 24 waves per CU reach 0.64-0.68 of 8 TB/s with the arithmetic removed, the staged spans of one 16-wave workgroup per CU
+// 0.71-0.74 (tools/copy_roof.hip, profiles/r04_copy_roof.json; a float4 copy: 0.79-0.81).  Regular hops <= N/2 that are multiples of
+// four samples; everything else takes STREAM == 1.
+template <class C, int MIXOP, int OUTK = 0, int STREAM = 0>
 __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_kernel(
     // Everything the table and frame loads depend on sits in the first 16 dwords of the kernel arguments: with
     // -amdgpu-kernarg-preload-count=16 those arrive in SGPRs with the wave, so the loads are issued without waiting for a
@@ -472,6 +498,12 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     __shared__ __attribute__((aligned(16))) cf s_tab[C::TLOC == 1 ? C::TAB_ELEMS : 2];
     __shared__ int s_lut[OUTK == 2 ? 256 : 1];
     static_assert(OUTK != 2 || (C::L == 64 && C::FPW == 1 && C::LDS_TOTAL + 1024 <= 160 * 1024), "single-kernel display path: one wavefront per frame");
+    constexpr bool BAT = STREAM != 0;   // rows (batches, or batch x channel) numbered through the launch
+    constexpr bool STG = STREAM == 2;   // input spans staged in LDS
+    static_assert(!BAT || OUTK == 0, "strided multi-batch launches write dB / power columns");
+    static_assert(!STG || (C::L == 64 && C::FPW == 1 && C::TLOC == 1), "staged input: one wavefront per frame");
+    constexpr int STAGE_BYTES = stage_bytes<C>;   // largest span (hop = N / 2)
+    static_assert(!STG || C::LDS_TOTAL + 2 * STAGE_BYTES <= 160 * 1024, "staged input: two spans beside the exchange buffers");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int L = C::L, P = C::P, M = C::M, R1 = C::R1, R2 = C::R2, R3 = C::R3, F = C::FPW;
     constexpr int U1 = C::U1, U2 = C::U2, U3 = C::U3;
@@ -502,8 +534,9 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     // bandwidth, see tools/copy_width_probe.py).  JSG_TRAVERSAL=chunk selects the old order (development A/B).
     const unsigned task_stride = a.chunked ? C::TPB : nblk * C::TPB;
     const unsigned task0 = (a.chunked ? lb * (unsigned)a.iters * C::TPB : lb * C::TPB) + slot0;   // first task of this wave
-    const int c0 = a.per_channel ? (int)blockIdx.y : a.c_begin;
-    const int c1 = a.per_channel ? (int)blockIdx.y + 1 : a.c_end;
+    // (STREAM: the channel of a per-channel row comes from the row number, see row_of; c0 / c1 then only give nc = 1)
+    const int c0 = a.per_channel ? (BAT ? 0 : (int)blockIdx.y) : a.c_begin;
+    const int c1 = a.per_channel ? (BAT ? 1 : (int)blockIdx.y + 1) : a.c_end;
     constexpr bool ONE = MIXOP == 3;
     const int nc = ONE ? 1 : c1 - c0;
     __builtin_assume(a.iters >= 1 && nc >= 1);   // (the launcher guarantees it) keeps the first frame's loads unconditional
@@ -512,17 +545,35 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     // again: they hold the same bits as that frame's own lanes and store them to the same column, so nothing is masked
     // OUTK == 2: group (= workgroup iteration) `it` of this workgroup -> image and first column inside that image (all scalar).  An
     // iteration past the last group (last round of the launch) repeats the last group and is not stored (`live` in the store phase).
+    // STREAM: the same with rows in the place of images.  A row's last group is moved back so that it ENDS with the row's last frame
+    // (it then overlaps the group before it: those columns are computed twice, same bits) -- the staged span of a group never leaves the
+    // row's input that way; the launcher sends rows shorter than TPB frames to STREAM == 1, which clamps frame by frame like STREAM == 0.
     auto group_of = [&](unsigned it, unsigned& image, unsigned& col0) -> bool {
         unsigned g = (task0 - slot0) / C::TPB + it * (task_stride / C::TPB);
         const bool inside = g < a.n_groups;
-        if (!inside) g = a.n_groups - 1;
+        // steps past the end (the last round of a launch whose step count is not a multiple of the grid): the display form repeats the
+        // last group and does not store it; the strided dB form starts over with the first groups -- recomputed and stored a second
+        // time with the same bits, but every surplus workgroup at a DIFFERENT place (all of them on the last group: hundreds of
+        // workgroups storing into the same eight columns, measured 0.44 instead of 0.58 of 8 TB/s with 9 workgroups per CU)
+        if (!inside) g = BAT ? g - a.n_groups : a.n_groups - 1;
         image = (unsigned)(((unsigned long long)g * a.img_magic) >> 40);
         col0 = (g - image * a.img_gpi) * C::TPB;
+        if constexpr (STG) { if (col0 + C::TPB > a.n_frames) col0 = a.n_frames - C::TPB; }
         return inside;
+    };
+    // row -> offsets of its input and of its ring: batch * stride (+ channel * pitch in per-channel mode)
+    auto row_of = [&](unsigned row, long long& in_off, long long& out_off) {
+        unsigned batch = row, ch = 0;
+        if (a.per_channel) {
+            batch = (unsigned)(((unsigned long long)row * a.bat_magic) >> 40);
+            ch = row - batch * a.bat_cpb;
+        }
+        in_off = (long long)batch * a.in_image_stride + (long long)ch * a.in_pitch;
+        out_off = (long long)batch * a.out_batch_stride + (long long)ch * a.out_cpitch;
     };
     auto task_of = [&](unsigned it, int f) -> unsigned {
         unsigned t;
-        if constexpr (OUTK == 2) {
+        if constexpr (OUTK == 2 || BAT) {
             unsigned image, col0;
             group_of(it, image, col0);
             t = col0 + slot0 + sub * F + f;
@@ -545,9 +596,54 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
             group_of(it, image, col0);
             start += (long long)image * a.in_image_stride;
         }
+        if constexpr (BAT) {
+            unsigned row, col0;
+            long long in_off, out_off;
+            group_of(it, row, col0);
+            row_of(row, in_off, out_off);
+            start += in_off;
+        }
         return reinterpret_cast<const f2u*>(a.in + (long long)c * a.in_pitch + start) + ll;
     };
+    // ---- STREAM == 2: the span of round s (the TPB frames of group `it`, channel c: (TPB - 1) hop + N contiguous samples) travels
+    //      into stage buffer s & 1 as 1 KB pieces, piece p by wave p % WPB; lanes past the end of the span stay off ----
+    char* const stage0 = smem_raw + C::LDS_BYTES;
+    constexpr int NPW = (STAGE_BYTES / 1024 + C::WPB - 1) / C::WPB;   // pieces per wave (the last ones may lie past the span: skipped)
+    auto stage = [&](int s) {
+        const unsigned it = (nc == 1) ? (unsigned)s : (unsigned)s / (unsigned)nc;
+        const int c = c0 + (s - (int)it * nc);
+        unsigned row, col0;
+        long long in_off, out_off;
+        group_of(it, row, col0);
+        row_of(row, in_off, out_off);
+        const char* g = reinterpret_cast<const char*>(a.in + (long long)c * a.in_pitch + in_off + (long long)(a.first_frame + col0) * a.hop);
+        char* l = stage0 + (s & 1) * STAGE_BYTES;
+        // Written as inline assembly on purpose: for an LDS-DMA that the compiler knows about, its wait-count pass puts an
+        // s_waitcnt vmcnt(0) in front of the next LDS read that may alias the target (every read of this kernel's dynamic LDS) --
+        // which would wait for the span that has just been requested.  The waits for these pieces are the counted ones at the top of
+        // a round (tests/test_isa_guard.py checks the instruction counts they rely on).
+        const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)l;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const unsigned off = (unsigned)(wave + i * C::WPB) * 1024u;
+            if (off + (unsigned)lane * 16u < a.span_bytes)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g + off + lane * 16), "s"(lbase + off) : "memory", "m0");
+        }
+    };
 
+#ifndef JSG_X_STG_PHASES
+#define JSG_X_STG_PHASES 2
+#endif
+    const bool late = STG && JSG_X_STG_PHASES == 2 && ((wave >> 2) & 1);   // wave-uniform
+    // one rendezvous of the staged form: my own pieces of the span that is needed next have landed (counted: they are older than the
+    // P + 1 stores of the column that was finished since), barrier (= everybody's have), then the pieces of span `next` are requested
+    auto span_sync = [&](bool counted, int next, bool have_next) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (counted) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(P + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (have_next) stage(next);
+    };
     // ---- lane tables first: two 16-byte LDS-DMA pieces per thread bring the tables from L2 straight into LDS (wave-uniform
     //      base + lane * 16 bytes, no VGPR round trip).  They are issued AHEAD of the frame loads: every wave's FFT start is
     //      gated by the workgroup barrier behind the tables, so they are the latency-critical load (frame loads first, or
@@ -568,7 +664,9 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     // ---- issue the loads of the first FFT round (software pipeline, one round ahead) ----
     f2u raw[F][P];
     if constexpr (C::ABL == 3) stA = __builtin_readcyclecounter();
-    if constexpr (C::ABL != 2) {
+    if constexpr (STG) {
+        stage(0);   // (the waves read it from LDS behind the barrier below; nothing is prefetched into registers)
+    } else if constexpr (C::ABL != 2) {
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             const f2u* src = frame_src(0, f);
@@ -582,8 +680,8 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         // the table pieces are older than the F * P frame loads of this wave: a counted vmcnt retires them and leaves the
         // frames in flight (an LDS-DMA is a pending LDS write on the VM counter; __syncthreads() would drain everything)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (compiler only) the frame loads stay above the counted wait
-        if constexpr (C::ABL != 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(F * P) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (C::ABL != 2 && !STG) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(F * P) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // (STG: tables and the first span)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if constexpr (C::ABL == 3) stC = __builtin_readcyclecounter();
         tBase = s_tab;
@@ -665,6 +763,26 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
 #pragma unroll
                 for (int m = 0; m < P; ++m) { raw[f][m].x = __int_as_float(0x3f800000 + lane + m + s + f); raw[f][m].y = 0.5f; }
         }
+        if constexpr (STG) {
+            // top of a step: this wave's pieces of round s were issued one round ago, AHEAD of that round's P + 1 column stores (the
+            // vector-memory counter retires in order), so a counted wait leaves those stores in flight; behind the workgroup barrier
+            // all pieces of the span have landed, and every wave has finished reading the OTHER buffer (it did so at the top of the
+            // round before), which the next span may therefore overwrite.
+            // Two phases: the waves 4-7 and 12-15 ("late": two per SIMD) meet that same barrier in the MIDDLE of their round s - 1
+            // instead (span_sync below, in front of stage 3): the two halves of the workgroup then run half a round apart for the whole
+            // launch -- while one half is in its LDS-heavy exchanges the other is in its butterflies -- with still one barrier per round.
+            if (!late) {
+                if (s > 0) span_sync(ONE || (s % nc) == 0, s + 1, !LAST);
+                else if (!LAST) stage(1);
+            } else if (s == 0 && !LAST) stage(1);   // (every wave carries pieces of every span)
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                // (hop is a multiple of four samples: the frame starts on a 16-byte boundary of the span, the pairs are 8-byte aligned)
+                const cf* lsrc = reinterpret_cast<const cf*>(stage0 + (s & 1) * STAGE_BYTES + (slot0 + sub * F + f) * a.hop * 4) + ll;
+#pragma unroll
+                for (int m = 0; m < P; ++m) { const cf v = lsrc[L * m]; raw[f][m].x = v.x; raw[f][m].y = v.y; }
+            }
+        }
         JSG_MARK(0);
         // ---- window multiply ----
 #pragma unroll
@@ -681,7 +799,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (s == 0) st1 = __builtin_readcyclecounter();
         }
-        if (C::ABL != 2 && !LAST) {   // the next round's frames travel while this one is transformed
+        if (C::ABL != 2 && !STG && !LAST) {   // the next round's frames travel while this one is transformed
 #pragma unroll
             for (int f = 0; f < F; ++f) {
                 const f2u* src = frame_src(s + 1, f);
@@ -775,6 +893,9 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         }
         if constexpr (!TWO) {
         frame_sync();
+        if constexpr (STG) {   // the late half's rendezvous: barrier s + 1, in the middle of its round s (none in its last round)
+            if (late && !LAST) span_sync(s > 0 && (ONE || (s % nc) == 0), s + 2, s + 2 < n_fft);
+        }
         JSG_MARK(5);
         // ---- stage 3: radix-R3 over n3; Z[k], k = t3 + R1 R2 k3 ----
 #pragma unroll
@@ -1046,7 +1167,13 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                 } else if (C::ABL == 2 ? (acc[f][0].x == 12345.678f) : true) {
                     // non-temporal dword stores, 256 contiguous bytes of the column per instruction (streaming the columns out
                     // instead of leaving them dirty in L2 removed the end-of-kernel write-back)
-                    const long long cofs = a.per_channel ? (long long)c0 * a.out_cpitch : 0ll;
+                    long long cofs = a.per_channel ? (long long)c0 * a.out_cpitch : 0ll;
+                    if constexpr (BAT) {   // the ring of this row (batch, or batch and channel)
+                        unsigned row, col0_;
+                        long long in_off;
+                        group_of(it, row, col0_);
+                        row_of(row, in_off, cofs);
+                    }
                     float* dstA = a.out + (long long)colA * a.out_pitch + cofs;
                     float* dstB = a.out + (long long)colB * a.out_pitch + cofs;
                     float* dst = a.out + (long long)col * a.out_pitch + cofs;
@@ -1140,16 +1267,17 @@ void fill_tables(std::vector<float2>& t, const float* window, double amp) {
 // Kernels that need more than 48 KB of dynamic LDS must be told so once per device.  jsg_plan_create does it for every
 // instantiation of the plan's size (so that the first launch may already sit inside a stream capture); the launch path
 // repeats the check for plans that are used on a device other than the one they were created on.
-template <class C, int MIXOP, int OUTK>
+template <class C, int MIXOP, int OUTK, int STREAM = 0>
 hipError_t ensure_lds_attr() {
     static std::atomic<bool> attr_done[64];   // set once per device; setting it twice from two threads is harmless
-    if (C::LDS_BYTES <= 48 * 1024) return hipSuccess;
+    constexpr int bytes = C::LDS_BYTES + (STREAM == 2 ? 2 * stage_bytes<C> : 0);
+    if (bytes <= 48 * 1024) return hipSuccess;
     int dev = 0;
     hipError_t err = hipGetDevice(&dev);
     if (err != hipSuccess) return err;
     if (dev >= 0 && dev < 64 && !attr_done[dev].load(std::memory_order_acquire)) {
-        err = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_db_kernel<C, MIXOP, OUTK>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_db_kernel<C, MIXOP, OUTK, STREAM>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (err != hipSuccess) return err;
         attr_done[dev].store(true, std::memory_order_release);
     }
@@ -1168,6 +1296,8 @@ hipError_t ensure_lds_attrs_of_plan() {
     if (e == hipSuccess) e = ensure_lds_attr<C, 3, 0>();
     if (e == hipSuccess) e = ensure_lds_attr<C, 0, 1>();
     if (e == hipSuccess) e = ensure_lds_attr<C, 3, 1>();
+    if (e == hipSuccess) e = ensure_lds_attr<C, 0, 0, 1>();
+    if (e == hipSuccess) e = ensure_lds_attr<C, 3, 0, 1>();
     if constexpr (image_ok<C>) {
         if (e == hipSuccess) e = ensure_lds_attr<C, 0, 2>();
         if (e == hipSuccess) e = ensure_lds_attr<C, 3, 2>();
@@ -1175,12 +1305,13 @@ hipError_t ensure_lds_attrs_of_plan() {
     return e;
 }
 
-template <class C, int MIXOP, int OUTK = 0>
+template <class C, int MIXOP, int OUTK = 0, int STREAM = 0>
 hipError_t launch_stft_mix(const StftKArgs& ka, dim3 grid, hipStream_t s) {
-    hipError_t err = ensure_lds_attr<C, MIXOP, OUTK>();
+    hipError_t err = ensure_lds_attr<C, MIXOP, OUTK, STREAM>();
     if (err != hipSuccess) return err;
     const int flags = (ka.regular ? 1 : 0) | (ka.per_channel ? 2 : 0) | (ka.xcd_remap ? 4 : 0) | (ka.chunked ? 8 : 0);
-    hipLaunchKernelGGL((stft_db_kernel<C, MIXOP, OUTK>), grid, dim3(C::WPB * 64), C::LDS_BYTES, s, ka.in, ka.in_pitch, ka.tab, ka.n_frames,
+    constexpr int lds = C::LDS_BYTES + (STREAM == 2 ? 2 * stage_bytes<C> : 0);
+    hipLaunchKernelGGL((stft_db_kernel<C, MIXOP, OUTK, STREAM>), grid, dim3(C::WPB * 64), lds, s, ka.in, ka.in_pitch, ka.tab, ka.n_frames,
                        ka.first_frame, ka.hop, flags, unsigned(ka.c_begin) | unsigned(ka.c_end) << 16, ka.iters, grid.x, ka.feedblocks, ka);
     return hipGetLastError();
 }
@@ -1207,6 +1338,15 @@ hipError_t launch_stft(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s)
     }
 }
 
+// strided multi-batch launches (STREAM == 1; Cfg1024S: STREAM == 2): the sum-mixed and the one-channel instantiations
+template <class C, int STREAM>
+hipError_t launch_stft_strided(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s) {
+    if (ka.argb || ka.idx) return hipErrorInvalidValue;
+    if (mixop == 3) return launch_stft_mix<C, 3, 0, STREAM>(ka, grid, s);
+    if (mixop == 0) return launch_stft_mix<C, 0, 0, STREAM>(ka, grid, s);
+    return hipErrorInvalidValue;
+}
+
 
 // ------------------------------------------------------------------------------------------------------------
 // Per-plan entry points.  The kernels of a plan are instantiated in exactly one translation unit (jsg_stft_a.hip or
@@ -1216,12 +1356,17 @@ hipError_t launch_stft(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s)
 #define JSG_FOR_EACH_PLAN(X) X(Cfg512) X(Cfg1024) X(Cfg2048) X(Cfg2048B) X(Cfg4096) X(Cfg4096B) X(Cfg8192)
 #define JSG_DECLARE_PLAN(C)                                                                   \
     hipError_t launch_##C(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s);          \
+    hipError_t launch_strided_##C(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s);  \
     hipError_t ensure_attrs_##C();
 JSG_FOR_EACH_PLAN(JSG_DECLARE_PLAN)
 #undef JSG_DECLARE_PLAN
 #define JSG_DEFINE_PLAN(C)                                                                                                  \
     hipError_t launch_##C(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s) { return launch_stft<C>(ka, mixop, grid, s); } \
+    hipError_t launch_strided_##C(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s) { return launch_stft_strided<C, 1>(ka, mixop, grid, s); } \
     hipError_t ensure_attrs_##C() { return ensure_lds_attrs_of_plan<C>(); }
+// Cfg1024S exists for the staged strided launches only (STREAM == 2; jsg_stft_a.hip)
+hipError_t launch_strided_Cfg1024S(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s);
+hipError_t ensure_attrs_Cfg1024S();
 // Loads the unit's code object onto the current device (the runtime loads lazily, 2.5 ms on first use: done when a plan is
 // created, not inside the audio thread's first jsg_process_block).
 hipError_t touch_module_a();

@@ -286,6 +286,30 @@ def stft_db_batches(plan: Plan, batches, hop: int, n_frames: int, *, stream: int
     check(lib().jsg_stft_db_launch_batches(plan._p, arr, len(batches), C.c_void_p(stream)))
 
 
+def _strided_args(plan: Plan, d_in, hop: int, n_frames: int, d_out, **kw):
+    """d_in float32 [k][channels][samples], d_out [k][W][pitch] (per-channel mode: [k][channels][W][pitch]): batch b = d_in[b] -> d_out[b]."""
+    assert d_in.dim() == 3 and d_in.stride(2) == 1 and d_out.shape[0] == d_in.shape[0] and d_out.stride(-1) == 1
+    a = _stft_args(plan, d_in[0], hop, n_frames, d_out[0], **kw)
+    return a, int(d_in.shape[0]), int(d_in.stride(0)), int(d_out.stride(0))
+
+
+def stft_db_strided(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, stream: int | None = None, **kw):
+    """jsg_stft_db_launch_strided: k independent batches of one geometry in ONE kernel launch on one stream (include/jsg.h)."""
+    import torch
+    a, k, s_in, s_out = _strided_args(plan, d_in, hop, n_frames, d_out, **kw)
+    if stream is None:
+        stream = torch.cuda.current_stream(d_in.device).cuda_stream
+    check(lib().jsg_stft_db_launch_strided(plan._p, C.byref(a), k, s_in, s_out, C.c_void_p(stream)))
+
+
+def stft_db_strided_kernel_name(plan: Plan, d_in, hop: int, n_frames: int, d_out, **kw) -> str:
+    """The kernel a strided launch takes: "Cfg1024S" (staged persistent form), else as stft_kernel_name for the total size."""
+    a, k, s_in, _ = _strided_args(plan, d_in, hop, n_frames, d_out, **kw)
+    buf = C.create_string_buffer(32)
+    check(lib().jsg_stft_db_strided_kernel_name(plan._p, C.byref(a), k, s_in, buf, 32))
+    return buf.value.decode()
+
+
 def stft_kernel_name(plan: Plan, d_in, hop: int, n_frames: int, d_out, **kw) -> str:
     """The kernel configuration jsg_stft_db_launch picks for this launch ("Cfg1024", "Cfg2048B", ...)."""
     a = _stft_args(plan, d_in, hop, n_frames, d_out, **kw)

@@ -63,6 +63,8 @@ def test_counted_wait_matches_the_emitted_frame_loads(tmp_path):
         n, lanes, tloc, fpw = vals[0], vals[4], vals[10], vals[12]
         if tloc != 1:
             continue
+        if re.search(r"EELi\dELi\dELi2EEEv", name):    # STREAM == 2 (staged input): its own guard below
+            continue
         expect = (n // 2 // lanes) * fpw
         dma = [i for i, ins in enumerate(body) if ins.startswith("global_load_lds_dwordx4") or (ins.startswith("buffer_load_dwordx4") and " lds" in ins)]
         assert dma, f"{name}: no LDS-DMA table pieces found"
@@ -79,7 +81,46 @@ def test_counted_wait_matches_the_emitted_frame_loads(tmp_path):
                                         f"s_waitcnt vmcnt({expect}): {between}")
         assert all(ins.startswith("global_load_dwordx2") for ins in between), f"{name}: unexpected frame-load form {sorted(set(between))[:3]}"
         checked += 1
-    assert checked >= 46, f"only {checked} instantiations checked"   # 7 plans x 6 + the ARGB-out forms of 1024 and 4096 "B"
+    assert checked >= 60, f"only {checked} instantiations checked"   # 7 plans x (6 + 2 strided) + the ARGB-out forms of 1024 and 4096 "B"
+
+
+def test_staged_kernels_counted_waits(tmp_path):
+    """The staged strided kernels (STREAM == 2, Cfg1024S) issue their LDS-DMA span pieces from inline assembly, invisible to the
+    compiler's wait-count pass, and retire them with `s_waitcnt vmcnt(P + 1)` + `s_barrier` at the top of the next round: right only
+    if a column's epilogue is EXACTLY P + 1 vector-memory instructions (the stores that are younger than the pieces), if nothing else
+    of the kernel is a vector-memory instruction, and if the compiler has not put a full vmcnt(0) wait of its own anywhere but
+    in front of a barrier."""
+    text = _disassemble(tmp_path)
+    checked = 0
+    for name, body in _functions(text):
+        if "stft_db_kernel" not in name or not re.search(r"EELi\dELi\dELi2EEEv", name):
+            continue
+        m = re.search(r"3CfgI(.*?)EE", name)
+        vals = [int(v) for v in re.findall(r"Li(\d+)E", m.group(1))]
+        n, lanes = vals[0], vals[4]
+        per_column = n // 2 // lanes + 1
+        vm = [(i, ins) for i, ins in enumerate(body) if VMEM.match(ins)]
+        assert all(ins.startswith(("global_load_lds_dwordx4", "global_store_dword ")) for _, ins in vm), f"{name}: unexpected vector-memory instruction"
+        runs, run = [], 0
+        for i, ins in enumerate(body):
+            if ins.startswith("global_store_dword "):
+                run += 1
+            elif run:
+                runs.append(run); run = 0
+        if run:
+            runs.append(run)
+        assert runs and all(r == per_column for r in runs), f"{name}: column epilogues of {runs} stores, the counted wait assumes {per_column}"
+        bars = [i for i, ins in enumerate(body) if ins.startswith("s_barrier")]
+        assert len(bars) >= 2
+        for k, b in enumerate(bars):
+            mm = re.match(r"s_waitcnt vmcnt\((\d+)\)$", body[b - 1])
+            assert mm, f"{name}: barrier {k} is not directly behind a counted wait: '{body[b - 1]}'"
+            assert int(mm.group(1)) in ((0,) if k == 0 else (0, per_column)), f"{name}: barrier {k} waits for vmcnt({mm.group(1)})"
+        assert any(re.match(rf"s_waitcnt vmcnt\({per_column}\)$", body[b - 1]) for b in bars[1:]), f"{name}: no counted wait found"
+        stray = [ins for i, ins in enumerate(body) if "vmcnt" in ins and not body[i + 1].startswith("s_barrier")]
+        assert not stray, f"{name}: a vmcnt wait that is not one of the kernel's own: {stray[:2]}"
+        checked += 1
+    assert checked == 2, f"{checked} staged instantiations found"
 
 
 def test_no_fused_lds_pairs_in_the_stft_kernels(tmp_path):
