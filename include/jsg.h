@@ -144,9 +144,7 @@ typedef struct jsg_stft_args {
                                 kernel otherwise.  1: always the small-workgroup kernel, 2: always "B".  The two round differently in
                                 the last bits (both inside the parity bound): callers that cut one stream into launches of
                                 very different sizes and need bit-identical columns pin one of them (the engine pins 1).
-                                jsg_stft_kernel_name() tells which one a launch takes.  1024 points, jsg_stft_db_launch_strided only:
-                                1 = never the staged form, 2 = the staged form wherever the geometry allows it (automatic: from four
-                                steps of sixteen frames per CU on).  Other sizes: ignored */
+                                jsg_stft_kernel_name() tells which one a launch takes.  Other sizes: ignored */
     int32_t reserved;        /* 0 */
 } jsg_stft_args;
 int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* args, void* stream);
@@ -190,15 +188,11 @@ int jsg_stft_db_launch_batches(const jsg_plan* plan, const jsg_stft_args* args, 
  * holds for the rows of EVERY batch) is the same for all batches.  The workgroups of the one launch walk through the columns of all
  * batches: lane tables loaded once per workgroup instead of once per eight frames, no ramp-up and drain per batch, the next columns in
  * flight while the current ones are transformed -- the rate of back-to-back launches without extra streams, hardware queues or issuing
- * threads (bench.py's default C2 step).
- *   1024 points, regular hop <= 512 that is a multiple of four samples, 16-byte aligned rows and strides, >= 16 frames per batch,
- *   AbsMean / Sum / Left / Right / per-channel: the STAGED form -- one persistent 16-wave workgroup per CU; the contiguous input span of
- *   sixteen frames is brought into LDS once by LDS-DMA (every sample leaves HBM and the L2 once, 1 KB per wave-instruction) one step
- *   ahead, and the waves read their frames from LDS.  Same radices, tables and operation order as jsg_stft_db_launch: bit-identical columns.
- *   Everything else: the plan's usual kernel walking through all batches (2048 / 4096 points: the plan rule of plan_select looks at
- *   the frames of the WHOLE launch; columns are those of single launches with plan_select pinned to that plan).
+ * threads (bench.py's default C2 step).  args->blocks_per_cu: workgroups per CU of the grid (0 = the library's choice).
+ *   2048 / 4096 points: the plan rule of plan_select looks at the frames of the WHOLE launch; columns are those of single launches
+ *   with plan_select pinned to that plan.  All other sizes: bit-identical to single launches.
  * Max / Min mixes have no strided kernel: they are launched batch by batch in stream order.  More than 2^20 workgroup steps go out as
- * several launches.  jsg_stft_db_strided_kernel_name tells the kernel ("Cfg1024S" = staged). */
+ * several launches.  jsg_stft_db_strided_kernel_name tells the kernel (as jsg_stft_kernel_name, for the total size). */
 int jsg_stft_db_launch_strided(const jsg_plan* plan, const jsg_stft_args* args, int n_batches, int64_t in_batch_stride,
                                int64_t out_batch_stride, void* stream);
 int jsg_stft_db_strided_kernel_name(const jsg_plan* plan, const jsg_stft_args* args, int n_batches, int64_t in_batch_stride, char* out,

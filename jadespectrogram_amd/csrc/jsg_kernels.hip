@@ -270,7 +270,7 @@ int jsg_plan_create(jsg_plan** out, int n, const float* window, float power_scal
     hipError_t err = hipSuccess;
     switch (n) {
         case 512: err = ensure_attrs_Cfg512(); break;
-        case 1024: err = ensure_attrs_Cfg1024(); if (err == hipSuccess) err = ensure_attrs_Cfg1024S(); break;
+        case 1024: err = ensure_attrs_Cfg1024(); break;
         case 2048: err = ensure_attrs_Cfg2048(); if (err == hipSuccess) err = ensure_attrs_Cfg2048B(); break;
         case 4096: err = ensure_attrs_Cfg4096(); if (err == hipSuccess) err = ensure_attrs_Cfg4096B(); break;
         case 8192: err = ensure_attrs_Cfg8192(); break;
@@ -330,27 +330,8 @@ namespace {
 struct BatchSpec {   // jsg_stft_db_launch_strided: `n` batches of the geometry in jsg_stft_args, batch b at in + b * in_stride, out_db + b * out_stride
     int n;
     long long in_stride, out_stride;
-    int mode;        // 1: STREAM == 1 (frame-by-frame loads), 2: STREAM == 2 (staged spans, Cfg1024S) -- chosen by strided_mode()
 };
 }  // namespace
-
-// Which form a strided launch of `n_batches` batches takes: 2 = the staged 1024-point kernel (one persistent 16-wave workgroup per CU,
-// input spans through LDS), 1 = the plan's usual kernel walking through all batches.  The staged form needs a regular hop <= n / 2 that
-// is a multiple of four samples, 16-byte aligned rows, rows of at least sixteen frames, a sum-type or one-channel mix, and enough work to
-// give every CU several steps (>= 4 steps of sixteen frames per CU); everything else takes form 1.  jsg_stft_args.plan_select = 1 | 2
-// pins form 1 / the staged form wherever the geometry allows it (JSG_STRIDED_MODE=1|2: the same from the environment, development A/B).
-static int strided_mode(const jsg_plan* plan, const jsg_stft_args* g, int n_batches, long long in_stride, int n_cu) {
-    static const int forced = [] { const char* e = getenv("JSG_STRIDED_MODE"); return e ? atoi(e) : 0; }();
-    if (plan->n != 1024 || forced == 1 || g->plan_select == 1) return 1;
-    const bool geometry = (long long)g->hop * g->feedblocks == plan->n && g->hop <= plan->n / 2 && g->hop % 4 == 0 && g->n_frames >= Cfg1024S::TPB &&
-                          ((reinterpret_cast<unsigned long long>(g->in) | (unsigned long long)(g->in_pitch * 4) | (unsigned long long)(in_stride * 4) |
-                            (unsigned long long)(g->first_frame * g->hop * 4)) & 15ull) == 0 &&
-                          g->mix_mode != JSG_MIX_MAX && g->mix_mode != JSG_MIX_MIN;
-    if (!geometry) return 1;
-    const long long rows = (long long)n_batches * (g->mix_mode == JSG_MIX_PER_CHANNEL ? g->channels : 1);
-    const long long steps = rows * ((g->n_frames + Cfg1024S::TPB - 1) / Cfg1024S::TPB);
-    return (forced == 2 || g->plan_select == 2 || steps >= 4ll * n_cu) ? 2 : 1;
-}
 
 static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const IndexOut* io, void* stream, const BatchSpec* bs = nullptr) {
     if (!plan || !g) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: null argument");
@@ -455,7 +436,6 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     // geometry (channels per column, frames, CU count) only; sub-launches of one stream that fall on different sides of the rule
     // agree within the float32 bound, not bit for bit (jsg.h: plan_select pins one plan).
     // (the single-kernel display path exists for the one-wavefront-per-frame plans: at 4096 points that is "B")
-    const bool staged = bs && bs->mode == 2;   // (1024 points: Cfg1024S shares Cfg1024's tables)
     const long long rows = bs ? (long long)bs->n * (ka.per_channel ? g->channels : 1) : 1;
     // (a strided launch is judged by the frames of ALL its rows: the "B" kernels then fill their rounds)
     const bool plan_b = (io && io->argb && plan->n == 4096) ||
@@ -464,7 +444,7 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     int tpb = 0;
     switch (plan->n) {
         case 512: tpb = Cfg512::TPB; break;
-        case 1024: tpb = staged ? Cfg1024S::TPB : Cfg1024::TPB; break;
+        case 1024: tpb = Cfg1024::TPB; break;
         case 2048: tpb = plan_b ? Cfg2048B::TPB : Cfg2048::TPB; break;
         case 4096: tpb = plan_b ? Cfg4096B::TPB : Cfg4096::TPB; break;
         case 8192: tpb = Cfg8192::TPB; break;
@@ -491,7 +471,6 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
         ka.bat_magic = ((1ull << 40) + (unsigned long long)ka.bat_cpb - 1) / (unsigned long long)ka.bat_cpb;
         ka.in_image_stride = bs->in_stride;
         ka.out_batch_stride = bs->out_stride;
-        ka.span_bytes = unsigned(((long long)(tpb - 1) * g->hop + plan->n) * 4);
     }
     const int ny = (ka.per_channel && !bs) ? g->channels : 1;
     if (ny > 65535) return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_db_launch: more than 65535 channels in per-channel mode");
@@ -503,20 +482,23 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     // workgroups per CU of the grid; the rest of the frames is looped over.  The "B" plans hold one workgroup per CU: a grid of
     // exactly that many keeps the tables and the prefetch pipeline alive across a workgroup's frames (16 384 mono 4096-point
     // frames: 65 vs 79 us with a grid of 8 per CU); the other plans do best with more workgroups than are resident.
-    const int bpc = staged ? 1 : g->blocks_per_cu > 0 ? g->blocks_per_cu : (blocks_per_cu_env > 0 ? blocks_per_cu_env : (plan_b ? 1 : 8));
+    const int bpc = g->blocks_per_cu > 0 ? g->blocks_per_cu : (blocks_per_cu_env > 0 ? blocks_per_cu_env : (plan_b ? 1 : 8));
     long long max_blocks = (long long)n_cu * bpc / ny;     // resident workgroups; the rest is looped over
     if (max_blocks < 64) max_blocks = 64;
     static const int max_blocks_env = [] { const char* e = getenv("JSG_STFT_MAX_BLOCKS"); return e ? atoi(e) : 0; }();   // development
     if (max_blocks_env > 0) max_blocks = max_blocks_env;
-    const int nblk = int(want < max_blocks ? want : max_blocks);
-    ka.iters = int((want + nblk - 1) / nblk);
+    // steps per workgroup first, then the smallest grid that covers the launch with that many: at most iters - 1 surplus steps in the
+    // last round (a grid of max_blocks would leave up to max_blocks - 1 of them: 9 workgroups per CU for 30 720 steps measured
+    // 0.54 against 0.58 of 8 TB/s at 8 per CU)
+    ka.iters = int((want + max_blocks - 1) / max_blocks);
+    const int nblk = int((want + ka.iters - 1) / ka.iters);
     const dim3 grid(nblk, ny);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipError_t err = hipSuccess;
     if (bs) {
         switch (plan->n) {
             case 512: err = launch_strided_Cfg512(ka, mixop, grid, s); break;
-            case 1024: err = staged ? launch_strided_Cfg1024S(ka, mixop, grid, s) : launch_strided_Cfg1024(ka, mixop, grid, s); break;
+            case 1024: err = launch_strided_Cfg1024(ka, mixop, grid, s); break;
             case 2048: err = plan_b ? launch_strided_Cfg2048B(ka, mixop, grid, s) : launch_strided_Cfg2048(ka, mixop, grid, s); break;
             case 4096: err = plan_b ? launch_strided_Cfg4096B(ka, mixop, grid, s) : launch_strided_Cfg4096(ka, mixop, grid, s); break;
             case 8192: err = launch_strided_Cfg8192(ka, mixop, grid, s); break;
@@ -697,8 +679,7 @@ int jsg_stft_db_launch_strided(const jsg_plan* plan, const jsg_stft_args* g, int
         one.out_db = g->out_db ? g->out_db + b0 * out_batch_stride : nullptr;
         if (nb == 1) rc = jsg_stft_db_launch(plan, &one, stream);
         else {
-            BatchSpec bs{nb, (long long)in_batch_stride, (long long)out_batch_stride, 1};
-            bs.mode = strided_mode(plan, &one, nb, in_batch_stride, cu_count_of_device(dev));
+            BatchSpec bs{nb, (long long)in_batch_stride, (long long)out_batch_stride};
             rc = stft_launch_impl(plan, &one, nullptr, stream, &bs);
         }
         if (rc != JSG_OK) return rc;
@@ -706,14 +687,14 @@ int jsg_stft_db_launch_strided(const jsg_plan* plan, const jsg_stft_args* g, int
     return JSG_OK;
 }
 
-// The kernel a strided launch takes, as text ("Cfg1024S" = the staged persistent form, else as jsg_stft_kernel_name for the total size).
+// The kernel a strided launch takes, as text (as jsg_stft_kernel_name, judged by the frames of the whole launch).
 int jsg_stft_db_strided_kernel_name(const jsg_plan* plan, const jsg_stft_args* g, int n_batches, int64_t in_batch_stride, char* out, int out_len) {
     if (!plan || !g || !out || out_len < 24 || n_batches < 1) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_strided_kernel_name: bad argument");
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) return jsg_fail(JSG_ERR_NO_DEVICE, "jsg_stft_db_strided_kernel_name: no device");
     if (n_batches == 1) return jsg_stft_kernel_name(plan, g, out, out_len);
     const int n_cu = cu_count_of_device(dev);
-    if (strided_mode(plan, g, n_batches, in_batch_stride, n_cu) == 2) { std::snprintf(out, size_t(out_len), "Cfg1024S"); return JSG_OK; }
+    (void)in_batch_stride;
     int nc = g->channels;
     if (g->mix_mode == JSG_MIX_LEFT || g->mix_mode == JSG_MIX_RIGHT || g->mix_mode == JSG_MIX_PER_CHANNEL) nc = 1;
     const long long rows = (long long)n_batches * (g->mix_mode == JSG_MIX_PER_CHANNEL ? g->channels : 1);

@@ -12,11 +12,6 @@ JSG_DEFINE_PLAN(Cfg1024)
 JSG_DEFINE_PLAN(Cfg2048)
 JSG_DEFINE_PLAN(Cfg2048B)
 JSG_DEFINE_PLAN(Cfg8192)
-hipError_t launch_strided_Cfg1024S(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s) { return launch_stft_strided<Cfg1024S, 2>(ka, mixop, grid, s); }
-hipError_t ensure_attrs_Cfg1024S() {
-    const hipError_t e = ensure_lds_attr<Cfg1024S, 0, 0, 2>();
-    return e == hipSuccess ? ensure_lds_attr<Cfg1024S, 3, 0, 2>() : e;
-}
 hipError_t touch_module_a() {
     hipFuncAttributes fa;
     return hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&stft_db_kernel<Cfg1024, 3>));

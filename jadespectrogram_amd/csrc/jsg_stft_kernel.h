@@ -279,10 +279,6 @@ using Cfg512 = Cfg<512, 8, 8, 4, 32, 36, 4, 33, 1, 8, 1, 2>;   // (a 80-VGPR bud
 #define JSG_X_WPS1024 6   // Left at 2 the ILP-first scheduler takes 88 for the mixing instantiations (two workgroups per CU): stereo -2..-4 % with the cap
 #endif
 using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, JSG_X_WPB1024, 1, JSG_X_WPS1024, JSG_X_FPW1024, JSG_X_ABL>;
-// The 1024-point plan as ONE persistent 16-wave workgroup per CU for the strided multi-batch launch (stft_db_kernel, STREAM == 2): the
-// same radices, layouts and tables as Cfg1024 (bit-identical results), sixteen frames per step.  16 x 4.5 KB of exchange + 10.7 KB of
-// tables leave room for two input spans of 34 KB (sixteen frames of hop 512), see STREAM below.  Four waves per SIMD: <= 128 VGPRs.
-using Cfg1024S = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 16, 1, 4>;
 #ifndef JSG_X_TWF2048      // factorised stage-2 / post tables (Cfg::TWF): 11.3 instead of 21.2 KB of tables, so that THREE 4-wave
 #define JSG_X_TWF2048 1    // workgroups fit a CU (12 waves instead of 8): stereo launches -9..-13 %, mono -1..-5 %
 #endif
@@ -379,7 +375,6 @@ struct StftKArgs {
     unsigned bat_cpb;             // rows per batch: channels in per-channel mode, else 1
     unsigned long long bat_magic; // ceil(2^40 / bat_cpb)
     long long out_batch_stride;   // floats between the rings of consecutive batches
-    unsigned span_bytes;          // STREAM == 2: bytes of the input span of one step = ((TPB - 1) * hop + N) * 4
 };
 
 // dB = 10*log10(p + 1e-11f) -- reference Spectrogram.cpp:107 with g_minValForLogSpectrogram (:36).
@@ -464,20 +459,13 @@ __device__ __forceinline__ cf mix_combine2(cf acc, cf pw) {
 #else
 #define JSG_MARK(k) do { } while (0)
 #endif
-// bytes of the largest input span of one step of the staged form (STREAM == 2): TPB frames at hop N / 2; a multiple of 1 KB
-template <class C>
-constexpr int stage_bytes = ((C::TPB - 1) * (C::N / 2) + C::N) * 4;
-
 // STREAM (jsg_stft_db_launch_strided: K independent batches of one geometry in ONE launch, OUTK == 0): 0 = one batch per launch;
 // 1 = the workgroups walk through the groups (TPB consecutive columns) of all batches, everything else as for one batch: tables loaded
-// once per workgroup and launch, the prefetch pipeline alive across batches, no ramp-up and drain per 4096 frames;
-// 2 = additionally the input is STAGED: the contiguous span of a step's TPB frames ((TPB - 1) hop + N samples: every sample once) is
-// brought into LDS by LDS-DMA -- 16 bytes per lane, 1 KB per wave-instruction, issued by all waves together right behind the step's
-// workgroup barrier, one step ahead, two buffers -- and the waves read their frames from LDS (the 50..87.5 % overlap is served there, no
-// VGPRs are spent on the prefetch).  Why: what HBM delivers depends on how tight the chip-wide access front is; the frame-by-frame
-// loads of 24 waves per CU reach 0.64-0.68 of 8 TB/s with the arithmetic removed, the staged spans of one 16-wave workgroup per CU
-// 0.71-0.74 (tools/copy_roof.hip, profiles/r04_copy_roof.json; a float4 copy: 0.79-0.81).  Regular hops <= N/2 that are multiples of
-// four samples; everything else takes STREAM == 1.
+// once per workgroup and launch, the prefetch pipeline alive across batches, no ramp-up and drain per 4096 frames.
+// (Round 4 also built STREAM == 2, "staged": one persistent 16-wave workgroup per CU whose input spans travel through LDS by LDS-DMA,
+// every sample once.  Bit-identical, and level with or behind this form everywhere it was measured -- its sixteen lock-stepped waves
+// per CU transform at most 1.0e9 frames/s where the 24 independent ones of this form reach 1.6e9; tools/experiments/r04_staged_span_kernel.patch,
+// DESIGN.md section 6.)
 template <class C, int MIXOP, int OUTK = 0, int STREAM = 0>
 __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_kernel(
     // Everything the table and frame loads depend on sits in the first 16 dwords of the kernel arguments: with
@@ -499,11 +487,8 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     __shared__ int s_lut[OUTK == 2 ? 256 : 1];
     static_assert(OUTK != 2 || (C::L == 64 && C::FPW == 1 && C::LDS_TOTAL + 1024 <= 160 * 1024), "single-kernel display path: one wavefront per frame");
     constexpr bool BAT = STREAM != 0;   // rows (batches, or batch x channel) numbered through the launch
-    constexpr bool STG = STREAM == 2;   // input spans staged in LDS
+    static_assert(STREAM == 0 || STREAM == 1, "see above");
     static_assert(!BAT || OUTK == 0, "strided multi-batch launches write dB / power columns");
-    static_assert(!STG || (C::L == 64 && C::FPW == 1 && C::TLOC == 1), "staged input: one wavefront per frame");
-    constexpr int STAGE_BYTES = stage_bytes<C>;   // largest span (hop = N / 2)
-    static_assert(!STG || C::LDS_TOTAL + 2 * STAGE_BYTES <= 160 * 1024, "staged input: two spans beside the exchange buffers");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int L = C::L, P = C::P, M = C::M, R1 = C::R1, R2 = C::R2, R3 = C::R3, F = C::FPW;
     constexpr int U1 = C::U1, U2 = C::U2, U3 = C::U3;
@@ -545,9 +530,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     // again: they hold the same bits as that frame's own lanes and store them to the same column, so nothing is masked
     // OUTK == 2: group (= workgroup iteration) `it` of this workgroup -> image and first column inside that image (all scalar).  An
     // iteration past the last group (last round of the launch) repeats the last group and is not stored (`live` in the store phase).
-    // STREAM: the same with rows in the place of images.  A row's last group is moved back so that it ENDS with the row's last frame
-    // (it then overlaps the group before it: those columns are computed twice, same bits) -- the staged span of a group never leaves the
-    // row's input that way; the launcher sends rows shorter than TPB frames to STREAM == 1, which clamps frame by frame like STREAM == 0.
+    // STREAM: the same with rows in the place of images.
     auto group_of = [&](unsigned it, unsigned& image, unsigned& col0) -> bool {
         unsigned g = (task0 - slot0) / C::TPB + it * (task_stride / C::TPB);
         const bool inside = g < a.n_groups;
@@ -558,7 +541,6 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         if (!inside) g = BAT ? g - a.n_groups : a.n_groups - 1;
         image = (unsigned)(((unsigned long long)g * a.img_magic) >> 40);
         col0 = (g - image * a.img_gpi) * C::TPB;
-        if constexpr (STG) { if (col0 + C::TPB > a.n_frames) col0 = a.n_frames - C::TPB; }
         return inside;
     };
     // row -> offsets of its input and of its ring: batch * stride (+ channel * pitch in per-channel mode)
@@ -605,45 +587,6 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         }
         return reinterpret_cast<const f2u*>(a.in + (long long)c * a.in_pitch + start) + ll;
     };
-    // ---- STREAM == 2: the span of round s (the TPB frames of group `it`, channel c: (TPB - 1) hop + N contiguous samples) travels
-    //      into stage buffer s & 1 as 1 KB pieces, piece p by wave p % WPB; lanes past the end of the span stay off ----
-    char* const stage0 = smem_raw + C::LDS_BYTES;
-    constexpr int NPW = (STAGE_BYTES / 1024 + C::WPB - 1) / C::WPB;   // pieces per wave (the last ones may lie past the span: skipped)
-    auto stage = [&](int s) {
-        const unsigned it = (nc == 1) ? (unsigned)s : (unsigned)s / (unsigned)nc;
-        const int c = c0 + (s - (int)it * nc);
-        unsigned row, col0;
-        long long in_off, out_off;
-        group_of(it, row, col0);
-        row_of(row, in_off, out_off);
-        const char* g = reinterpret_cast<const char*>(a.in + (long long)c * a.in_pitch + in_off + (long long)(a.first_frame + col0) * a.hop);
-        char* l = stage0 + (s & 1) * STAGE_BYTES;
-        // Written as inline assembly on purpose: for an LDS-DMA that the compiler knows about, its wait-count pass puts an
-        // s_waitcnt vmcnt(0) in front of the next LDS read that may alias the target (every read of this kernel's dynamic LDS) --
-        // which would wait for the span that has just been requested.  The waits for these pieces are the counted ones at the top of
-        // a round (tests/test_isa_guard.py checks the instruction counts they rely on).
-        const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)l;
-#pragma unroll
-        for (int i = 0; i < NPW; ++i) {
-            const unsigned off = (unsigned)(wave + i * C::WPB) * 1024u;
-            if (off + (unsigned)lane * 16u < a.span_bytes)
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g + off + lane * 16), "s"(lbase + off) : "memory", "m0");
-        }
-    };
-
-#ifndef JSG_X_STG_PHASES
-#define JSG_X_STG_PHASES 2
-#endif
-    const bool late = STG && JSG_X_STG_PHASES == 2 && ((wave >> 2) & 1);   // wave-uniform
-    // one rendezvous of the staged form: my own pieces of the span that is needed next have landed (counted: they are older than the
-    // P + 1 stores of the column that was finished since), barrier (= everybody's have), then the pieces of span `next` are requested
-    auto span_sync = [&](bool counted, int next, bool have_next) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (counted) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(P + 1) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (have_next) stage(next);
-    };
     // ---- lane tables first: two 16-byte LDS-DMA pieces per thread bring the tables from L2 straight into LDS (wave-uniform
     //      base + lane * 16 bytes, no VGPR round trip).  They are issued AHEAD of the frame loads: every wave's FFT start is
     //      gated by the workgroup barrier behind the tables, so they are the latency-critical load (frame loads first, or
@@ -664,9 +607,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     // ---- issue the loads of the first FFT round (software pipeline, one round ahead) ----
     f2u raw[F][P];
     if constexpr (C::ABL == 3) stA = __builtin_readcyclecounter();
-    if constexpr (STG) {
-        stage(0);   // (the waves read it from LDS behind the barrier below; nothing is prefetched into registers)
-    } else if constexpr (C::ABL != 2) {
+    if constexpr (C::ABL != 2) {
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             const f2u* src = frame_src(0, f);
@@ -680,8 +621,8 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         // the table pieces are older than the F * P frame loads of this wave: a counted vmcnt retires them and leaves the
         // frames in flight (an LDS-DMA is a pending LDS write on the VM counter; __syncthreads() would drain everything)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (compiler only) the frame loads stay above the counted wait
-        if constexpr (C::ABL != 2 && !STG) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(F * P) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // (STG: tables and the first span)
+        if constexpr (C::ABL != 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(F * P) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if constexpr (C::ABL == 3) stC = __builtin_readcyclecounter();
         tBase = s_tab;
@@ -763,26 +704,6 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
 #pragma unroll
                 for (int m = 0; m < P; ++m) { raw[f][m].x = __int_as_float(0x3f800000 + lane + m + s + f); raw[f][m].y = 0.5f; }
         }
-        if constexpr (STG) {
-            // top of a step: this wave's pieces of round s were issued one round ago, AHEAD of that round's P + 1 column stores (the
-            // vector-memory counter retires in order), so a counted wait leaves those stores in flight; behind the workgroup barrier
-            // all pieces of the span have landed, and every wave has finished reading the OTHER buffer (it did so at the top of the
-            // round before), which the next span may therefore overwrite.
-            // Two phases: the waves 4-7 and 12-15 ("late": two per SIMD) meet that same barrier in the MIDDLE of their round s - 1
-            // instead (span_sync below, in front of stage 3): the two halves of the workgroup then run half a round apart for the whole
-            // launch -- while one half is in its LDS-heavy exchanges the other is in its butterflies -- with still one barrier per round.
-            if (!late) {
-                if (s > 0) span_sync(ONE || (s % nc) == 0, s + 1, !LAST);
-                else if (!LAST) stage(1);
-            } else if (s == 0 && !LAST) stage(1);   // (every wave carries pieces of every span)
-#pragma unroll
-            for (int f = 0; f < F; ++f) {
-                // (hop is a multiple of four samples: the frame starts on a 16-byte boundary of the span, the pairs are 8-byte aligned)
-                const cf* lsrc = reinterpret_cast<const cf*>(stage0 + (s & 1) * STAGE_BYTES + (slot0 + sub * F + f) * a.hop * 4) + ll;
-#pragma unroll
-                for (int m = 0; m < P; ++m) { const cf v = lsrc[L * m]; raw[f][m].x = v.x; raw[f][m].y = v.y; }
-            }
-        }
         JSG_MARK(0);
         // ---- window multiply ----
 #pragma unroll
@@ -799,7 +720,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (s == 0) st1 = __builtin_readcyclecounter();
         }
-        if (C::ABL != 2 && !STG && !LAST) {   // the next round's frames travel while this one is transformed
+        if (C::ABL != 2 && !LAST) {   // the next round's frames travel while this one is transformed
 #pragma unroll
             for (int f = 0; f < F; ++f) {
                 const f2u* src = frame_src(s + 1, f);
@@ -893,9 +814,6 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         }
         if constexpr (!TWO) {
         frame_sync();
-        if constexpr (STG) {   // the late half's rendezvous: barrier s + 1, in the middle of its round s (none in its last round)
-            if (late && !LAST) span_sync(s > 0 && (ONE || (s % nc) == 0), s + 2, s + 2 < n_fft);
-        }
         JSG_MARK(5);
         // ---- stage 3: radix-R3 over n3; Z[k], k = t3 + R1 R2 k3 ----
 #pragma unroll
@@ -1270,7 +1188,7 @@ void fill_tables(std::vector<float2>& t, const float* window, double amp) {
 template <class C, int MIXOP, int OUTK, int STREAM = 0>
 hipError_t ensure_lds_attr() {
     static std::atomic<bool> attr_done[64];   // set once per device; setting it twice from two threads is harmless
-    constexpr int bytes = C::LDS_BYTES + (STREAM == 2 ? 2 * stage_bytes<C> : 0);
+    constexpr int bytes = C::LDS_BYTES;
     if (bytes <= 48 * 1024) return hipSuccess;
     int dev = 0;
     hipError_t err = hipGetDevice(&dev);
@@ -1310,7 +1228,7 @@ hipError_t launch_stft_mix(const StftKArgs& ka, dim3 grid, hipStream_t s) {
     hipError_t err = ensure_lds_attr<C, MIXOP, OUTK, STREAM>();
     if (err != hipSuccess) return err;
     const int flags = (ka.regular ? 1 : 0) | (ka.per_channel ? 2 : 0) | (ka.xcd_remap ? 4 : 0) | (ka.chunked ? 8 : 0);
-    constexpr int lds = C::LDS_BYTES + (STREAM == 2 ? 2 * stage_bytes<C> : 0);
+    constexpr int lds = C::LDS_BYTES;
     hipLaunchKernelGGL((stft_db_kernel<C, MIXOP, OUTK, STREAM>), grid, dim3(C::WPB * 64), lds, s, ka.in, ka.in_pitch, ka.tab, ka.n_frames,
                        ka.first_frame, ka.hop, flags, unsigned(ka.c_begin) | unsigned(ka.c_end) << 16, ka.iters, grid.x, ka.feedblocks, ka);
     return hipGetLastError();
@@ -1338,7 +1256,7 @@ hipError_t launch_stft(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s)
     }
 }
 
-// strided multi-batch launches (STREAM == 1; Cfg1024S: STREAM == 2): the sum-mixed and the one-channel instantiations
+// strided multi-batch launches (STREAM == 1): the sum-mixed and the one-channel instantiations
 template <class C, int STREAM>
 hipError_t launch_stft_strided(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s) {
     if (ka.argb || ka.idx) return hipErrorInvalidValue;
@@ -1364,9 +1282,6 @@ JSG_FOR_EACH_PLAN(JSG_DECLARE_PLAN)
     hipError_t launch_##C(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s) { return launch_stft<C>(ka, mixop, grid, s); } \
     hipError_t launch_strided_##C(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s) { return launch_stft_strided<C, 1>(ka, mixop, grid, s); } \
     hipError_t ensure_attrs_##C() { return ensure_lds_attrs_of_plan<C>(); }
-// Cfg1024S exists for the staged strided launches only (STREAM == 2; jsg_stft_a.hip)
-hipError_t launch_strided_Cfg1024S(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s);
-hipError_t ensure_attrs_Cfg1024S();
 // Loads the unit's code object onto the current device (the runtime loads lazily, 2.5 ms on first use: done when a plan is
 // created, not inside the audio thread's first jsg_process_block).
 hipError_t touch_module_a();

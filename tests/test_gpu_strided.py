@@ -1,6 +1,6 @@
 """jsg_stft_db_launch_strided: K independent batches of one geometry in ONE kernel launch must give, bit for bit, the columns of K
-single jsg_stft_db_launch calls -- in both forms (the plan's kernel walking through all batches; the staged 1024-point kernel whose
-input spans travel through LDS), for ragged frame counts, ring wrap, every hop class, mixes, per-channel rows, unaligned inputs."""
+single jsg_stft_db_launch calls -- for ragged frame counts, ring wrap, every hop class, mixes, per-channel rows, unaligned inputs, every
+plan, grids whose step count is not a multiple of the grid size (surplus steps start over with the first groups)."""
 import numpy as np
 import pytest
 
@@ -26,7 +26,7 @@ def _batches(torch, K, C, n_samples, seed, lead=0):
 
 
 def _run_case(jsg, oracle, torch, n, C, F, K, hop, fb=None, mix=None, W=None, ring_pos=0, first_frame=0, lead=0, linear=False,
-              plan_select=0, expect_kernel=None, window=None, same_input=False):
+              plan_select=0, expect_kernel=None, window=None, same_input=False, blocks_per_cu=0):
     mix = jsg.capi.MIX_ABSMEAN if mix is None else mix
     fb = fb if fb is not None else max(1, n // hop)
     H, pitch = n // 2 + 1, (n // 2 + 1 + 31) // 32 * 32
@@ -51,7 +51,7 @@ def _run_case(jsg, oracle, torch, n, C, F, K, hop, fb=None, mix=None, W=None, ri
         pin = 2 if name.endswith("B") else 1
     for b in range(K):
         jsg.stft_db(plan, d_in[b], hop, F, ref[b], plan_select=pin, **kw)
-    jsg.stft_db_strided(plan, d_in, hop, F, got, plan_select=plan_select, **kw)
+    jsg.stft_db_strided(plan, d_in, hop, F, got, plan_select=plan_select, blocks_per_cu=blocks_per_cu, **kw)
     torch.cuda.synchronize()
     assert torch.equal(got[..., :H], ref[..., :H]), f"{name}: strided launch differs from {K} single launches"
     assert torch.equal(got, ref), f"{name}: something outside the columns was written"
@@ -60,48 +60,48 @@ def _run_case(jsg, oracle, torch, n, C, F, K, hop, fb=None, mix=None, W=None, ri
 
 @pytest.mark.parametrize("F,K,hop,ring", [(4096, 5, 512, (4096, 0)), (4096, 5, 512, (5000, 3000)), (1000, 7, 512, (1000, 0)), (1001, 9, 256, (1200, 700)),
                                            (16, 300, 512, (16, 5)), (17, 300, 128, (40, 39)), (4096, 3, 64, (4096, 0)), (333, 40, 4, (400, 100))])
-def test_staged_form_equals_single_launches_mono(jsg, oracle, torch_cuda, F, K, hop, ring):
-    """1024 points, one channel: the staged persistent kernel (pinned with plan_select = 2 where the launch is small) for whole and
-    ragged rows (the last step of a row is moved back: columns computed twice, same bits), ring wrap, overlaps from 50 % to 99.6 %."""
-    name = _run_case(jsg, oracle, torch_cuda, 1024, 1, F, K, hop, W=ring[0], ring_pos=ring[1], plan_select=2, expect_kernel="Cfg1024S")
-    assert name == "Cfg1024S"
+def test_strided_equals_single_launches_mono_1024(jsg, oracle, torch_cuda, F, K, hop, ring):
+    """1024 points, one channel: whole and ragged rows, ring wrap, overlaps from 50 % to 99.6 %."""
+    assert _run_case(jsg, oracle, torch_cuda, 1024, 1, F, K, hop, W=ring[0], ring_pos=ring[1]) == "Cfg1024"
 
 
-def test_staged_form_is_the_automatic_choice_for_the_headline_geometry(jsg, oracle, torch_cuda):
-    assert _run_case(jsg, oracle, torch_cuda, 1024, 1, 4096, 6, 512) == "Cfg1024S"          # 6 x 256 steps >= 4 per CU
-    assert _run_case(jsg, oracle, torch_cuda, 1024, 1, 512, 4, 512) == "Cfg1024"            # too little work: the usual kernel, strided
-    assert _run_case(jsg, oracle, torch_cuda, 1024, 1, 4096, 6, 512, plan_select=1) == "Cfg1024"
+@pytest.mark.parametrize("bpc", [1, 2, 3, 5, 7, 9, 24, 100])
+def test_grid_sizes_that_do_not_divide_the_step_count(jsg, oracle, torch_cuda, bpc):
+    """30 batches x 125 groups = 3750 steps over grids of 256 x bpc workgroups: surplus steps of the last round recompute the FIRST groups
+    (same bits, stored twice) instead of piling up on the last one."""
+    _run_case(jsg, oracle, torch_cuda, 1024, 1, 1000, 30, 512, blocks_per_cu=bpc)
+    _run_case(jsg, oracle, torch_cuda, 1024, 2, 333, 11, 256, blocks_per_cu=bpc, W=400, ring_pos=399)
 
 
 @pytest.mark.parametrize("C,mix", [(2, "absmean"), (3, "absmean"), (8, "absmean"), (2, "left"), (2, "right"), (5, "sum"), (8, "per_channel"), (3, "per_channel")])
-def test_staged_form_mixes_and_per_channel_rows(jsg, oracle, torch_cuda, C, mix):
+def test_mixes_and_per_channel_rows(jsg, oracle, torch_cuda, C, mix):
     m = {"absmean": jsg.capi.MIX_ABSMEAN, "left": jsg.capi.MIX_LEFT, "right": jsg.capi.MIX_RIGHT, "sum": jsg.capi.MIX_SUM,
          "per_channel": jsg.capi.MIX_PER_CHANNEL}[mix]
-    _run_case(jsg, oracle, torch_cuda, 1024, C, 700, 6, 512, mix=m, W=800, ring_pos=500, plan_select=2, expect_kernel="Cfg1024S")
-    _run_case(jsg, oracle, torch_cuda, 1024, C, 700, 6, 512, mix=m, W=800, ring_pos=500, plan_select=1, expect_kernel="Cfg1024")
+    _run_case(jsg, oracle, torch_cuda, 1024, C, 700, 6, 512, mix=m, W=800, ring_pos=500, expect_kernel="Cfg1024")
 
 
-def test_staged_form_linear_power_first_frame_and_other_windows(jsg, oracle, torch_cuda):
-    _run_case(jsg, oracle, torch_cuda, 1024, 2, 900, 5, 512, linear=True, plan_select=2, expect_kernel="Cfg1024S")
-    _run_case(jsg, oracle, torch_cuda, 1024, 1, 900, 5, 512, first_frame=37, plan_select=2, expect_kernel="Cfg1024S")
-    _run_case(jsg, oracle, torch_cuda, 1024, 1, 900, 5, 256, first_frame=3, plan_select=2, window=oracle.WIN_FLATTOP, expect_kernel="Cfg1024S")
-    _run_case(jsg, oracle, torch_cuda, 1024, 1, 640, 5, 512, same_input=True, plan_select=2, expect_kernel="Cfg1024S")     # in_batch_stride = 0
+def test_linear_power_first_frame_other_windows_and_shared_input(jsg, oracle, torch_cuda):
+    _run_case(jsg, oracle, torch_cuda, 1024, 2, 900, 5, 512, linear=True)
+    _run_case(jsg, oracle, torch_cuda, 1024, 1, 900, 5, 512, first_frame=37)
+    _run_case(jsg, oracle, torch_cuda, 1024, 1, 900, 5, 256, first_frame=3, window=oracle.WIN_FLATTOP)
+    _run_case(jsg, oracle, torch_cuda, 1024, 1, 640, 5, 512, same_input=True)     # in_batch_stride = 0
 
 
 @pytest.mark.parametrize("what", ["unaligned", "hop1024", "perc10", "hop_odd", "short_rows", "max"])
-def test_geometries_the_staged_form_does_not_take(jsg, oracle, torch_cuda, what):
-    """... go through the usual kernel (still ONE launch for all batches), or batch by batch for Max / Min: same columns."""
+def test_odd_geometries(jsg, oracle, torch_cuda, what):
+    """Unaligned rows, no overlap, the reference's irregular perc10 hop, odd hops, rows shorter than a workgroup step; Max / Min go out
+    batch by batch: same columns."""
     cap = jsg.capi
     if what == "unaligned":
-        _run_case(jsg, oracle, torch_cuda, 1024, 1, 800, 6, 512, lead=1, plan_select=2, expect_kernel="Cfg1024")
+        _run_case(jsg, oracle, torch_cuda, 1024, 1, 800, 6, 512, lead=1, expect_kernel="Cfg1024")
     elif what == "hop1024":
-        _run_case(jsg, oracle, torch_cuda, 1024, 1, 800, 6, 1024, plan_select=2, expect_kernel="Cfg1024")
+        _run_case(jsg, oracle, torch_cuda, 1024, 1, 800, 6, 1024, expect_kernel="Cfg1024")
     elif what == "perc10":
-        _run_case(jsg, oracle, torch_cuda, 1024, 2, 800, 6, 102, fb=10, plan_select=2, expect_kernel="Cfg1024")
+        _run_case(jsg, oracle, torch_cuda, 1024, 2, 800, 6, 102, fb=10, expect_kernel="Cfg1024")
     elif what == "hop_odd":
-        _run_case(jsg, oracle, torch_cuda, 1024, 1, 800, 6, 205, fb=1, plan_select=2, expect_kernel="Cfg1024")
+        _run_case(jsg, oracle, torch_cuda, 1024, 1, 800, 6, 205, fb=1, expect_kernel="Cfg1024")
     elif what == "short_rows":
-        _run_case(jsg, oracle, torch_cuda, 1024, 1, 9, 50, 512, plan_select=2, expect_kernel="Cfg1024")
+        _run_case(jsg, oracle, torch_cuda, 1024, 1, 9, 50, 512, expect_kernel="Cfg1024")
     else:
         _run_case(jsg, oracle, torch_cuda, 1024, 3, 500, 4, 512, mix=cap.MIX_MAX)
         _run_case(jsg, oracle, torch_cuda, 1024, 3, 500, 4, 512, mix=cap.MIX_MIN)

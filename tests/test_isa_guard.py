@@ -85,7 +85,8 @@ def test_counted_wait_matches_the_emitted_frame_loads(tmp_path):
 
 
 def test_staged_kernels_counted_waits(tmp_path):
-    """The staged strided kernels (STREAM == 2, Cfg1024S) issue their LDS-DMA span pieces from inline assembly, invisible to the
+    """(Applies to builds with tools/experiments/r04_staged_span_kernel.patch; the product build holds no such kernel.)
+    The staged strided kernels (STREAM == 2, Cfg1024S) issue their LDS-DMA span pieces from inline assembly, invisible to the
     compiler's wait-count pass, and retire them with `s_waitcnt vmcnt(P + 1)` + `s_barrier` at the top of the next round: right only
     if a column's epilogue is EXACTLY P + 1 vector-memory instructions (the stores that are younger than the pieces), if nothing else
     of the kernel is a vector-memory instruction, and if the compiler has not put a full vmcnt(0) wait of its own anywhere but
@@ -120,7 +121,7 @@ def test_staged_kernels_counted_waits(tmp_path):
         stray = [ins for i, ins in enumerate(body) if "vmcnt" in ins and not body[i + 1].startswith("s_barrier")]
         assert not stray, f"{name}: a vmcnt wait that is not one of the kernel's own: {stray[:2]}"
         checked += 1
-    assert checked == 2, f"{checked} staged instantiations found"
+    assert checked == 0 or checked == 2, f"{checked} staged instantiations found"
 
 
 def test_no_fused_lds_pairs_in_the_stft_kernels(tmp_path):
