@@ -1,38 +1,36 @@
 #!/usr/bin/env python3
 """Headline benchmark: STFT frames/sec (1024-pt, 50 % hop) on N MI355X, with the kernel's HBM roofline fraction.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
-torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by torch.distributed.run with one
+rank per GPU.  Rank 0 prints ONE JSON line.
 
 What a step is
 --------------
-A step is a FIXED, stated group of launches of the fused kernel over synthetic batches that are resident in HBM, so the
-result does not depend on how many steps the driver asks for:
+A step is a FIXED, stated number of kernel dispatches over synthetic batches that are resident in HBM, all on ONE stream, in
+order, issued by plain C calls -- no extra streams, no hardware-queue setting, no issuing threads, no hipGraph:
 
-  c2 (default, BASELINE.json configs[1]): one step = 1024 launches x 4096 frames (mono 48 kHz, 1024-point FFT, hop 512,
-      Hann) = 4 194 304 frames.  The launches of a step are independent batches; they are handed to the library in ONE call,
-      jsg_stft_db_launch_batches: stream-ordered with respect to the caller's stream like a single launch, spread over the
-      caller's stream plus three streams of the library and issued by two host threads, so the ramp-up and drain of one launch
-      overlap the others (include/jsg.h).  `value` = frames of all ranks / wall time of the K steps.
-      `--streams N` instead issues over N caller-owned streams (jsg_stft_db_launch_many_threads) -- sweeps and the tracer.
-  c3 (configs[2]): one step = 64 launches x 4096 columns of 8-channel 2048-point frames, 75 % overlap, AbsMean mix,
-      through the same call (two working streams: these kernels run one workgroup per CU).
-  c5 (configs[4]): independent images of 1875 columns (10 s), stereo 96 kHz, 4096-point FFT, 87.5 % overlap, fused STFT ->
-      palette index -> ARGB image in ONE kernel.  The images have one geometry and lie at a fixed stride, so a step hands them to the
-      library as strided batches (jsg_stft_image_launch_strided): one step = 3 launches x a whole rotation of images (~39) =
-      ~117 images; the workgroups of a launch walk through the columns of all its images.  `--images-per-launch 1 [--streams S]`
-      launches the images one by one instead (jsg_stft_image_launch; 128 per step, three hipGraphs on three streams by default).
-  `--streams 1` times every configuration in order on one stream (that is also what `roofline` reports, see below).
+  c2 (default, BASELINE.json configs[1]: mono 48 kHz, 1024-point FFT, hop 512, Hann, batches of 4096 frames): one step =
+      16 dispatches of jsg_stft_db_launch_strided, each covering the whole rotation of 64 independent 4096-frame batches
+      (64 x 4096 frames per dispatch) = 4 194 304 frames per step.  The workgroups of a dispatch walk through the batches.
+  c3 (configs[2]: 8 channels, 2048 points, 75 % overlap, AbsMean): one step = 4 dispatches x 12 batches x 4096 columns.
+  c5 (configs[4]: stereo 96 kHz, 4096 points, 87.5 % overlap -> ARGB): one step = 3 dispatches of jsg_stft_image_launch_strided,
+      each a whole rotation of ~44 independent 1875-column images.
+  `--mode single` times one dispatch per batch instead (the literal "4096 frames/launch" of configs[1]; also what the
+  `one_batch_per_launch` block of every default line reports, from a short in-order run).
 
 The batches rotate over ~1 GB of distinct buffers (about four times the 256 MiB Infinity Cache; `--nbuf` overrides), so every
-launch streams from and to HBM.  Before the W warm-up steps the same launches run for about 0.3 s so that the clocks have settled.
+dispatch streams from and to HBM.  Before the W warm-up steps the same work runs for about 0.5 s so that the clocks have settled.
 
-`roofline` is the per-kernel view: the same launches, one at a time in order on ONE stream (a hipGraph replay, timed
-with HIP events on that stream); achieved = algorithmic bytes per launch / average launch duration.  rocprofv3's
-per-dispatch duration of `bench.py --streams 1` (profiles/) is the cross-check.
+`value` = units of all ranks / wall time of the K timed steps (barrier + synchronize on both sides, max over ranks).
+`roofline`: the timed region IS a sequence of back-to-back dispatches of one kernel on one stream, so its per-dispatch duration is
+measured live with HIP events on that stream around the K steps: achieved = algorithmic bytes per dispatch / that duration, and
+`timed_region_frac` (bytes of the K steps / wall) is the same number up to the host's last synchronize.  rocprofv3's per-dispatch
+average of the same command is committed under profiles/ (tools/profile_bench.sh) and quoted beside it when it was recorded with
+the same kernel sources.  `calibration` = what a tuned float4 copy (jsg_calib_copy_launch) reaches on this box: the measured roof.
 
-Every rank works on its own batches (weak scaling; the path shards by channel / stream, there is no data-path
-collective); RCCL carries only the barriers and the max-over-ranks time.
+Every rank works on its own batches (weak scaling; the path shards by channel / stream, there is no data-path collective); RCCL
+carries only the barriers and the max-over-ranks time.  At N = 1 the default line also carries the c3 and c5 results (`extra`), from
+child processes that run BEFORE this process touches the GPU.
 """
 from __future__ import annotations
 
@@ -47,33 +45,27 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues per device (default 4, read when the runtime
-# starts) in creation order, and torch's own streams take part: with too few queues two of the bench's busy streams land on ONE
-# hardware queue and serialise (round 3, nine streams in the process: 0.79 / 0.41 / 0.84 / 1.08 / 1.08e9 frames/s at 4 / 6 / 8 / 12 /
-# 16 queues).  What must stay at four is the number of BUSY queues (a fifth makes the command processor time-slice: 0.35e9).
-if not os.environ.get("JSG_KEEP_HW_QUEUES"):      # (libjsg.so applies the same default when it is loaded before the HIP runtime starts)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-
 ROTATION_BYTES = 1.0e9       # distinct input + output bytes the timed launches rotate over (>> 256 MiB Infinity Cache)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
-HBM_ACHIEVABLE_GBS = 6300.0  # ... and about 6.3 TB/s achievable (measured streaming copy)
+HBM_GUIDE_COPY_GBS = 6290.0  # ... and 6.29 TB/s for a float4 copy in the guide; bench.py measures its own (calibrate_copy)
 
 # name -> workload (algorithmic bytes count every input sample once and every output value once)
 CONFIGS = {
-    "c2": dict(n=1024, hop=512, channels=1, frames=4096, fs=48000.0, colour=False, launches_per_step=1024, streams=4,
+    "c2": dict(n=1024, hop=512, channels=1, frames=4096, fs=48000.0, colour=False, dispatches_per_step=16, batches_per_dispatch=64,
                metric="STFT frames/sec (1024-pt, 50% hop)", unit="frames/s",
-               workload="configs[1]: mono 48 kHz, 1024-pt FFT, 512 hop, Hann, 4096 frames/launch, input + dB ring resident in HBM"),
-    "c3": dict(n=2048, hop=512, channels=8, frames=4096, fs=48000.0, colour=False, launches_per_step=64, streams=2,
+               workload="configs[1]: mono 48 kHz, 1024-pt FFT, 512 hop, Hann, batched 4096 frames/launch -- K such batches per kernel dispatch "
+                        "(see step), inputs + dB rings resident in HBM"),
+    "c3": dict(n=2048, hop=512, channels=8, frames=4096, fs=48000.0, colour=False, dispatches_per_step=4, batches_per_dispatch=12,
                metric="STFT frames/sec (2048-pt, 75% overlap, 8 channels mixed to one column)", unit="frames/s",
                workload="configs[2]: 8-channel 48 kHz, 2048-pt FFT, 512 hop (75 % overlap), Hann, AbsMean mix, 4096 columns/launch"),
-    "c5": dict(n=4096, hop=512, channels=2, frames=1875, fs=96000.0, colour=True, launches_per_step=128, streams=3, batch_launches_per_step=3,
+    "c5": dict(n=4096, hop=512, channels=2, frames=1875, fs=96000.0, colour=True, dispatches_per_step=3, batches_per_dispatch=44,
                metric="STFT->ARGB columns/sec (4096-pt, 87.5% overlap, stereo 96 kHz)", unit="columns/s",
                workload="configs[4]: stereo 96 kHz, 4096-pt FFT, 512 hop (87.5 % overlap), AbsMean, Jade LUT -50..50 dB -> ARGB image, "
                         "independent images of 1875 columns (10 s), fused STFT -> palette index -> ARGB"),
 }
 
 
-def algorithmic_bytes_per_launch(c) -> int:
+def algorithmic_bytes_per_batch(c) -> int:
     H = c["n"] // 2 + 1
     per_column = 4 * c["hop"] * c["channels"] + (4 * H if c["colour"] else 4 * H)   # input once + one dB column, or one ARGB column
     return per_column * c["frames"]
@@ -309,61 +301,94 @@ def parity_report(jsg, c, plan, d_in_host, win):
             "note": "float64 DFT of the float32 windowed frames is the yardstick; indices: Jade, 256 colours, -50..50 dB"}
 
 
+def calibrate_copy(lib, torch, stream):
+    """The roof on THIS box: jsg_calib_copy_launch (float4, non-temporal loads and stores, non-looping grid) on buffers that rotate over
+    2 x 1 GiB -- 1 GiB per launch, and the byte counts of one 65 536-frame launch (134 MB each way) and of one C2 batch (8.4 MB each way).
+    Bytes read + bytes written / time of back-to-back launches on one stream (HIP events)."""
+    pool = 1 << 30
+    src = torch.empty(pool // 4, dtype=torch.float32, device="cuda").uniform_(-1, 1)
+    dst = torch.empty(pool // 4, dtype=torch.float32, device="cuda")
+    out = {}
+    for name, nbytes in (("1GiB", pool), ("134MB", 134348800), ("8.4MB", 8396800)):
+        nrot = max(1, pool // nbytes)
+        reps = max(6, min(300, (6 << 30) // nbytes))
+
+        def go(i):
+            off = (i % nrot) * nbytes
+            rc = lib.jsg_calib_copy_launch(ctypes.c_void_p(src.data_ptr() + off), ctypes.c_void_p(dst.data_ptr() + off), nbytes, ctypes.c_void_p(stream.cuda_stream))
+            assert rc == 0
+        with torch.cuda.stream(stream):
+            for i in range(3):
+                go(i)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for i in range(reps):
+                go(i)
+            e1.record(stream)
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        out[name] = {"bytes_each_way": nbytes, "us": round(us, 2), "GBps": round(2 * nbytes / us / 1e3, 1), "frac_of_8p0": round(2 * nbytes / us / 1e3 / HBM_PEAK_GBS, 4)}
+    del src, dst
+    return {"kernel": "jsg_calib_copy_launch: float4 copy, non-temporal loads + stores, one thread per 16 bytes, read + written bytes / time",
+            "peak_copy_GBps": out["1GiB"]["GBps"], "sizes": out,
+            "guide": "MI355X_MICROARCH.md: 6.29 TB/s measured for a float4 copy (0.79 of the 8.0 TB/s spec)"}
+
+
+def run_extra_config(cfg):
+    """c3 / c5 as a child process (started before this process touches the GPU): their headline numbers for the driver's line."""
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-boundary",
+                            "--no-extra", "--no-calibration", "--sub-run"], capture_output=True, text=True, timeout=400)
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        return {"metric": j["metric"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "step": j["config"]["step"],
+                "workload": j["config"]["workload"], "kernel": j["roofline"]["kernel"],
+                "roofline": {k: j["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_source", "avg_dispatch_us", "algorithmic_bytes_per_dispatch",
+                                                           "timed_region_frac", "frac_rocprof", "traffic", "second_roof") if k in j["roofline"]},
+                "parity": {k: j["parity"][k] for k in ("kernel", "frac_bins_rel_power_err_gt_1e-5", "max_err_relative_to_frame_peak", "colour_index_flips_end_to_end",
+                                                       "pixels_checked", "strided_pixels_differing_from_single_launches", "strided_columns_differing_from_single_launches")
+                           if k in j.get("parity", {})}}
+    except Exception as e:   # a reported figure, never a reason to lose the bench line
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
-    ap.add_argument("--launches-per-step", type=int, default=0, help="launches in one step (default: the configuration's)")
-    ap.add_argument("--nbuf", type=int, default=0, help="distinct batches rotated through (default: enough for > 256 MiB)")
-    ap.add_argument("--streams", type=int, default=0, help="HIP streams of the timed region (default: 4 for c2, 2 for c3, 3 for c5; 1 = in order)")
-    ap.add_argument("--images-per-launch", type=int, default=0, help="c5: images of one jsg_stft_image_launch_strided call (default: the whole rotation, "
-                                                                     "~39; 1 = one jsg_stft_image_launch per image, on --streams streams)")
-    ap.add_argument("--issue-threads", type=int, default=2, help="host threads issuing the launches of a step (c2, streams > 1)")
-    ap.add_argument("--blocks-per-cu", type=int, default=1, help="workgroups per CU of each launch when launches overlap")
+    ap.add_argument("--dispatches-per-step", type=int, default=0, help="kernel dispatches in one step (default: the configuration's)")
+    ap.add_argument("--nbuf", type=int, default=0, help="batches (c5: images) per dispatch = distinct batches rotated through (default: ~1 GB worth)")
+    ap.add_argument("--mode", choices=("strided", "single"), default="strided",
+                    help="strided: one dispatch covers all batches of the rotation (default); single: one dispatch per batch, in order")
+    ap.add_argument("--blocks-per-cu", type=int, default=0, help="workgroups per CU of a dispatch (0: the library's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sub-run", action="store_true", help="(internal) this process is the default-environment child of another bench.py")
     ap.add_argument("--no-parity", action="store_true", help="skip the `parity` block (the profile scripts: its few launches would mix into the tracer's averages)")
     ap.add_argument("--no-boundary", action="store_true", help="skip the `boundary` block (jsg_process_block latency, PCIe-inclusive rate)")
-    ap.add_argument("--gate", action="store_true", help="with --no-graph: hold the stream with a gate kernel while the host enqueues a step's "
-                                                        "launches, so that they run back to back even under a tracer (short kernels: c2)")
-    ap.add_argument("--no-graph", action="store_true", help="issue the in-order launches from the host instead of replaying a hipGraph "
-                                                            "(rocprofv3 does not see kernels inside graph replays, and its counter passes crash on them)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the c3 / c5 child runs of the default line")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the copy-roof calibration")
+    ap.add_argument("--no-single", action="store_true", help="skip the one-batch-per-dispatch leg")
+    ap.add_argument("--sub-run", action="store_true", help="(internal) this process is a child of another bench.py")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work at all: exercises the N-rank plumbing (barriers, reductions, "
                                                            "JSON) on a machine without GPUs; value is null")
     args = ap.parse_args()
     c = dict(CONFIGS[args.config])
-    # c5: the images of a step are independent and of one geometry -> by default they go to the library as strided batches, one kernel
-    # launch for a whole rotation of images (jsg_stft_image_launch_strided); --images-per-launch 1 (or --streams > 1) launches them one by one
-    batch = bool(c["colour"]) and args.images_per_launch != 1 and args.streams <= 1
-    lps = args.launches_per_step or (c["batch_launches_per_step"] if batch else c["launches_per_step"])
-    n_streams = 1 if batch else max(1, args.streams or c["streams"])
+    dps = args.dispatches_per_step or c["dispatches_per_step"]
 
     import numpy as np
     import torch
 
-    # child processes (git, and make if the C oracle is stale) are started BEFORE anything initialises the GPU
+    # child processes (git, make for a stale C oracle, the c3 / c5 runs, the latency test) are started BEFORE anything initialises the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     commit = _git_commit()
     if not args.dry_run and not args.no_cpu_baseline and world == 1:   # the CPU baseline leg runs at N = 1 only
         from oracle import oracle_c
         oracle_c.load()
-    default_env = None
-    if not args.dry_run and not args.no_boundary and world == 1 and not args.sub_run and not c["colour"] and not args.streams:
-        # the same timed region in a child process WITHOUT the eight hardware queues (GPU_MAX_HW_QUEUES unset, the library told to keep
-        # its hands off): what a host sees that neither sets the variable nor loads libjsg.so before the HIP runtime starts
-        env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
-        env["JSG_KEEP_HW_QUEUES"] = "1"
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", args.config, "--steps", "10", "--warmup", "3", "--no-cpu-baseline",
-                                "--no-boundary", "--sub-run"], env=env, capture_output=True, text=True, timeout=300)
-            sl = json.loads(r.stdout.strip().splitlines()[-1])
-            default_env = {"GPU_MAX_HW_QUEUES": "unset (runtime default 4)", "value": sl["value"], "unit": sl["unit"],
-                           "timed_region_frac_of_8p0": sl["roofline"]["timed_region_frac_of_8p0"], "steps": 10}
-        except Exception as e:
-            default_env = {"error": f"{type(e).__name__}: {e}"[:200]}
+    extra = None
+    if not args.dry_run and not args.no_extra and world == 1 and not args.sub_run and args.config == "c2":
+        extra = {cfg: run_extra_config(cfg) for cfg in ("c3", "c5")}
     boundary = None
     if not args.dry_run and not args.no_boundary and world == 1:
         boundary = {"process_block_latency": boundary_latency_subprocess()}
@@ -398,381 +423,213 @@ def main():
 
     n, hop, C, F = c["n"], c["hop"], c["channels"], c["frames"]
     H = n // 2 + 1
-    algo = algorithmic_bytes_per_launch(c)
-    units_per_launch = F if c["colour"] else F * C     # columns for c5, frames (FFTs) otherwise
+    fb = n // hop
+    algo_batch = algorithmic_bytes_per_batch(c)
+    units_per_batch = F if c["colour"] else F * C      # columns for c5, frames (FFTs) otherwise
+    strided = args.mode == "strided"
 
     run_step = None
-    ipl, nrot = 1, 0                                  # images per launch (c5 batches), distinct launch argument sets
-    inorder_us = eager_us = None
-    copy_us = None
-    parity = None
-    nbuf = 0
+    nbuf = args.nbuf or c["batches_per_dispatch"]
+    bpd = nbuf if strided else 1                      # batches per dispatch
+    dispatch_us = single_us = None
+    parity = calibration = None
+    kernel_label = None
     if not args.dry_run:
         import jadespectrogram_amd as jsg
         from jadespectrogram_amd import capi
-        from jadespectrogram_amd.spectrogram import _stft_args
         lib = capi.lib()
         win = jsg.window(jsg.capi.WIN_HANN, n)
         plan = jsg.Plan(n, win)
-        n_samples = F * hop + (n - hop)
+        n_samples = (F * hop + (n - hop) + 3) // 4 * 4
         pitch = (H + 31) // 32 * 32
-        idx_pitch = (H + 63) // 64 * 64
         img_pitch = (F + 31) // 32 * 32
-        per_batch = C * n_samples * 4 + ((0 if batch else F * idx_pitch) + H * img_pitch * 4 if c["colour"] else F * pitch * 4)
-        # Rotation: distinct batches worth ~1 GB, about four times the 256 MiB Infinity Cache.  (Rounds 1-2 rotated over 0.3 GB; the
-        # --nbuf sweep of round 3 -- profiles/r03_c2_nbuf_sweep.json -- showed that a good part of those reads still hit the cache:
-        # C2 1.35e9 frames/s at 0.35 GB, 1.12e9 at 0.7 GB, 1.10e9 at 1.4 GB.)
-        nbuf = args.nbuf or max(2, int(ROTATION_BYTES // per_batch) + 1)
-        while n_streams > 1 and nbuf % n_streams:   # a batch must always land on the same stream (its ring is rewritten in order)
-            nbuf += 1
-        if batch:                                   # the rotation is cut into launches of `ipl` images each
-            ipl = min(args.images_per_launch or nbuf, nbuf)
-            nbuf = (nbuf + ipl - 1) // ipl * ipl
-            nrot = nbuf // ipl
-            algo *= ipl
-            units_per_launch *= ipl
+        per_batch = C * n_samples * 4 + (H * img_pitch * 4 if c["colour"] else F * pitch * 4)
+        if not args.nbuf and abs(nbuf * per_batch - ROTATION_BYTES) > 0.25 * ROTATION_BYTES:   # (a changed geometry: keep ~1 GB)
+            nbuf = max(2, int(ROTATION_BYTES // per_batch) + 1)
+            bpd = nbuf if strided else 1
         base = synth_audio(C, n_samples + nbuf * 64, fs=c["fs"], seed=1234 + 1000 * rank)   # SURVEY 8d signal
-        d_in, d_out, d_img, d_scr = [], [], [], []
-        d_in_all = torch.empty((nbuf, C, n_samples), dtype=torch.float32, device="cuda")      # contiguous: image b = d_in_all[b] (strided launches)
-        d_img_all = torch.zeros((nbuf, H, img_pitch), dtype=torch.int32, device="cuda") if c["colour"] else None
+        d_in = torch.empty((nbuf, C, n_samples), dtype=torch.float32, device="cuda")          # batch b = d_in[b]
         for b in range(nbuf):
-            d_in_all[b].copy_(torch.from_numpy(np.ascontiguousarray(base[:, b * 64:b * 64 + n_samples])))
-            d_in.append(d_in_all[b])
-            if c["colour"]:
-                d_img.append(d_img_all[b])
-                d_scr.append(torch.zeros((F, idx_pitch), dtype=torch.uint8, device="cuda") if not batch else None)
-            else:
-                d_out.append(torch.empty((F, pitch), dtype=torch.float32, device="cuda"))
-        if not batch:
-            nrot = nbuf
+            d_in[b].copy_(torch.from_numpy(np.ascontiguousarray(base[:, b * 64:b * 64 + n_samples])))
+        d_img = torch.zeros((nbuf, H, img_pitch), dtype=torch.int32, device="cuda") if c["colour"] else None
+        d_out = None if c["colour"] else torch.empty((nbuf, F, pitch), dtype=torch.float32, device="cuda")
         d_lut = torch.from_numpy(jsg.colormap_lut(256, jsg.capi.CM_JADE)).cuda() if c["colour"] else None
-        fb = n // hop
-        kernel_label = None
-        if batch:
-            two = jsg.stft_image_strided_needs_scratch(plan, d_in_all[:ipl], hop, F, d_lut, -50.0, 50.0, d_img_all[:ipl, :, :F], None, feedblocks=fb,
-                                                       mix_mode=jsg.capi.MIX_ABSMEAN)
-            assert not two, "the strided C5 launch is expected to take the single-kernel form"
-            kernel_label = (f"stft_db_kernel<Cfg4096B, AbsMean, ARGB out> (jsg_stft_image_launch_strided: {ipl} images in one kernel launch, "
-                            "the workgroups colour their columns)")
-        elif c["colour"]:
-            two = jsg.stft_image_needs_scratch(plan, d_in[0], hop, F, d_lut, -50.0, 50.0, d_img[0][:, :F], d_scr[0], feedblocks=fb,
-                                               mix_mode=jsg.capi.MIX_ABSMEAN)
-            kernel_label = ("stft_db_kernel<4096, AbsMean, index out> + colormap_kernel (jsg_stft_image_launch, two kernels)" if two else
-                            "stft_db_kernel<Cfg4096B, AbsMean, ARGB out> (jsg_stft_image_launch, one kernel: the workgroup colours its columns)")
+        mixk = dict(feedblocks=fb, mix_mode=jsg.capi.MIX_ABSMEAN)
         one = torch.cuda.Stream()
+        if c["colour"]:
+            if strided:
+                two = jsg.stft_image_strided_needs_scratch(plan, d_in[:bpd], hop, F, d_lut, -50.0, 50.0, d_img[:bpd, :, :F], None, **mixk)
+            else:
+                two = jsg.stft_image_needs_scratch(plan, d_in[0], hop, F, d_lut, -50.0, 50.0, d_img[0][:, :F], None, plan_select=2, **mixk)
+            assert not two, "the C5 launches are expected to take the single-kernel form"
+            kernel_label = "stft_db_kernel<Cfg4096B, AbsMean, ARGB out> (the workgroups colour their own columns)"
+        else:
+            kname = jsg.stft_db_strided_kernel_name(plan, d_in[:bpd], hop, F, d_out[:bpd], **mixk)
+            kernel_label = f"stft_db_kernel<{kname}, {'one channel per column' if C == 1 else 'AbsMean'}, dB out{', strided' if bpd > 1 else ''}>"
 
-        def launch(b, stream_handle, bpc=0):
-            if batch:       # launch b of the rotation: images [b * ipl, (b + 1) * ipl)
-                jsg.stft_image_strided(plan, d_in_all[b * ipl:(b + 1) * ipl], hop, F, d_lut, -50.0, 50.0, d_img_all[b * ipl:(b + 1) * ipl, :, :F], None,
-                                       feedblocks=fb, mix_mode=jsg.capi.MIX_ABSMEAN, stream=stream_handle)
+        def dispatch(stream_handle, b=0):
+            if c["colour"] and strided:
+                jsg.stft_image_strided(plan, d_in, hop, F, d_lut, -50.0, 50.0, d_img[:, :, :F], None, stream=stream_handle, **mixk)
             elif c["colour"]:
-                jsg.stft_image(plan, d_in[b], hop, F, d_lut, -50.0, 50.0, d_img[b][:, :F], d_scr[b], feedblocks=fb,
-                               mix_mode=jsg.capi.MIX_ABSMEAN, stream=stream_handle)
+                jsg.stft_image(plan, d_in[b], hop, F, d_lut, -50.0, 50.0, d_img[b][:, :F], None, plan_select=2, stream=stream_handle, **mixk)
+            elif strided:
+                jsg.stft_db_strided(plan, d_in, hop, F, d_out, blocks_per_cu=args.blocks_per_cu, stream=stream_handle, **mixk)
             else:
-                jsg.stft_db(plan, d_in[b], hop, F, d_out[b], feedblocks=fb, mix_mode=jsg.capi.MIX_ABSMEAN, blocks_per_cu=bpc,
-                            stream=stream_handle)
+                jsg.stft_db(plan, d_in[b], hop, F, d_out[b], blocks_per_cu=args.blocks_per_cu, stream=stream_handle, **mixk)
 
-        # ---- the in-order group of one step as a hipGraph on ONE stream (per-kernel view; the timed region of c3 / c5) ----
-        with torch.cuda.stream(one):
-            for b in range(min(nrot, lps)):
-                launch(b, one.cuda_stream)
-            torch.cuda.synchronize()
-        gate = {"cycles_per_ms": 0.0, "cycles": 0}
-        if args.gate:
-            # --gate: a gate kernel (torch.cuda._sleep: spins for a fixed number of cycles, i.e. it always ends) holds a stream
-            # while the host enqueues a whole step behind it, so the step's launches run BACK TO BACK on the GPU even when the host
-            # is slow (under rocprofv3 it needs ~11 us per launch).  Calibrated here: spin cycles per millisecond.
-            with torch.cuda.stream(one):
-                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                g0.record(one); torch.cuda._sleep(20_000_000); g1.record(one)
-                torch.cuda.synchronize()
-            gate["cycles_per_ms"] = 20_000_000 / max(g0.elapsed_time(g1), 1e-3)
-        if args.no_graph:
-            # Host-issued launches (rocprofv3 does not see kernels inside graph replays).  With --gate they still run back to
-            # back; without it every 5 us dispatch of c2 starts on an idle GPU and reads ~1 us longer (6.3 vs 5.7 us).  For the
-            # long kernels of c3 / c5 the tracer's own per-dispatch work shows up instead when they run back to back, so they are
-            # traced ungated.
-
-            def gated(issue):
-                def run():
-                    with torch.cuda.stream(one):
-                        if gate["cycles"] and args.gate:
-                            torch.cuda._sleep(gate["cycles"])
-                        t_i = time.perf_counter()
-                        issue()
-                        t_i = (time.perf_counter() - t_i) * 1e3
-                    # next time the gate outlasts the host's issue time by half (bounded: at most 0.5 s)
-                    gate["cycles"] = int(min(500.0, 1.5 * t_i + 0.2) * gate["cycles_per_ms"])
-                return run
-            if c["colour"]:
-                def _issue():
-                    for i in range(lps):
-                        launch(i % nrot, one.cuda_stream)
-                replay_inorder = gated(_issue)
-            else:
-                arr1 = (capi.StftArgs * lps)()
-                for i in range(lps):
-                    a_i = _stft_args(plan, d_in[i % nbuf], hop, F, d_out[i % nbuf], feedblocks=fb, mix_mode=jsg.capi.MIX_ABSMEAN)
-                    ctypes.memmove(ctypes.byref(arr1, i * ctypes.sizeof(capi.StftArgs)), ctypes.byref(a_i), ctypes.sizeof(capi.StftArgs))
-                one_arr = (ctypes.c_void_p * 1)(one.cuda_stream)
-
-                replay_inorder = gated(lambda: capi.check(lib.jsg_stft_db_launch_many(plan._p, arr1, lps, one_arr, 1)))
-        else:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.stream(one):
-                with torch.cuda.graph(graph, stream=one):
-                    for i in range(lps):
-                        launch(i % nrot, one.cuda_stream)
-            torch.cuda.synchronize()
-
-            def replay_inorder():
-                with torch.cuda.stream(one):
-                    graph.replay()
-
-        if n_streams > 1 and c["colour"] and args.no_graph:
-            # ---- the same independent images, host-issued round-robin over the streams (for the tracer: it does not see kernels
-            #      inside graph replays); --gate holds every stream while the host enqueues the step ----
-            streams = [torch.cuda.Stream() for _ in range(n_streams)]
-
-            def run_step():
-                if args.gate and gate["cycles"]:
-                    for st in streams:
-                        with torch.cuda.stream(st):
-                            torch.cuda._sleep(gate["cycles"])
-                t_i = time.perf_counter()
-                for i in range(lps):
-                    launch(i % nbuf, streams[i % n_streams].cuda_stream)
-                if args.gate:
-                    gate["cycles"] = int(min(500.0, 1.5 * (time.perf_counter() - t_i) * 1e3 + 0.2) * gate["cycles_per_ms"])
-        elif n_streams > 1 and c["colour"]:
-            # ---- independent images on n_streams streams: one hipGraph per stream (image i goes to stream i % n_streams, so a
-            #      batch's scratch and image are always rewritten in order), replayed together: the colour kernel of one image
-            #      runs beside the STFT kernel of the next ----
-            streams = [torch.cuda.Stream() for _ in range(n_streams)]
-            graphs = []
-            for si, st in enumerate(streams):
-                gph = torch.cuda.CUDAGraph()
-                with torch.cuda.stream(st):
-                    with torch.cuda.graph(gph, stream=st):
-                        for i in range(si, lps, n_streams):
-                            launch(i % nbuf, st.cuda_stream)
-                graphs.append(gph)
-            torch.cuda.synchronize()
-
-            def run_step():
-                for st, gph in zip(streams, graphs):
-                    with torch.cuda.stream(st):
-                        gph.replay()
-        elif n_streams > 1:
-            # ---- the overlapped group: lps independent launches from ONE C call over n_streams streams ----
-            arr = (capi.StftArgs * lps)()
-            for i in range(lps):
-                a_i = _stft_args(plan, d_in[i % nbuf], hop, F, d_out[i % nbuf], feedblocks=fb, mix_mode=jsg.capi.MIX_ABSMEAN,
-                                 blocks_per_cu=args.blocks_per_cu)
-                ctypes.memmove(ctypes.byref(arr, i * ctypes.sizeof(capi.StftArgs)), ctypes.byref(a_i), ctypes.sizeof(capi.StftArgs))
-            streams = [torch.cuda.Stream() for _ in range(n_streams)]
-            sarr = (ctypes.c_void_p * n_streams)(*[st.cuda_stream for st in streams])
-            use_pool = not args.streams and not args.gate    # default: the LIBRARY's launch pool (its own streams and issuing threads)
-
-            def run_step():
-                if use_pool:
-                    capi.check(lib.jsg_stft_db_launch_batches(plan._p, arr, lps, ctypes.c_void_p(one.cuda_stream)))
-                    return
-                # --gate (for the tracer, tools/profile_overlap.sh): every stream is held by a bounded spin kernel while the host
-                # enqueues the step, so the launches overlap on the GPU exactly as they do when the host keeps up
-                if args.gate and gate["cycles"]:
-                    for st in streams:
-                        with torch.cuda.stream(st):
-                            torch.cuda._sleep(gate["cycles"])
-                t_i = time.perf_counter()
-                capi.check(lib.jsg_stft_db_launch_many_threads(plan._p, arr, lps, sarr, n_streams, max(1, args.issue_threads)))
-                if args.gate:   # next time the gates outlast the host's issue time by half (bounded: at most 0.5 s)
-                    gate["cycles"] = int(min(500.0, 1.5 * (time.perf_counter() - t_i) * 1e3 + 0.2) * gate["cycles_per_ms"])
-        else:
-            run_step = replay_inorder
+        def run_step():
+            h = one.cuda_stream
+            for i in range(dps):
+                dispatch(h, i % nbuf)
     else:
         def run_step():
             time.sleep(0.001)
 
-    # ---- settle the clocks (about 0.3 s of the same work), W warm-up steps, then EXACTLY K timed steps ----
+    # ---- settle the clocks (about 0.5 s of the same work), W warm-up steps, then EXACTLY K timed steps ----
     prewarm_s = 0.0
+    ev0 = ev1 = None
     if not args.dry_run:
         t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < 0.3:
+        while time.perf_counter() - t_pre < 0.5:
             run_step()
             sync()
         prewarm_s = time.perf_counter() - t_pre
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(args.warmup):
         run_step()
     sync(); barrier(); sync()
     t0 = time.perf_counter()
+    if ev0 is not None:
+        ev0.record(one)
     for _ in range(args.steps):
         run_step()
+    if ev1 is not None:
+        ev1.record(one)
     sync()
     t1 = time.perf_counter()
     barrier(); sync()
     wall = t1 - t0
+    if ev0 is not None:
+        dispatch_us = ev0.elapsed_time(ev1) * 1e3 / (args.steps * dps)     # per-dispatch duration of the timed region itself
 
-    if not args.dry_run:
-        # ---- per-kernel view: the same launches in order on one stream, HIP events on that stream ----
-        reps = max(3, min(args.steps, 20))
-        replay_inorder(); torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        if args.no_graph:   # the gate is part of replay_inorder(): the events go between the gate and the launches
-            tot = 0.0
-            for _ in range(reps):
-                with torch.cuda.stream(one):
-                    if gate["cycles"] and args.gate:
-                        torch.cuda._sleep(gate["cycles"])
-                    ev0.record(one)
-                    if c["colour"]:
-                        for i in range(lps):
-                            launch(i % nrot, one.cuda_stream)
-                    else:
-                        capi.check(lib.jsg_stft_db_launch_many(plan._p, arr1, lps, one_arr, 1))
-                    ev1.record(one)
-                torch.cuda.synchronize()
-                tot += ev0.elapsed_time(ev1)
-            inorder_us = tot * 1e3 / (reps * lps)
-        else:
-            with torch.cuda.stream(one):
-                ev0.record(one)
-                for _ in range(reps):
-                    replay_inorder()
-                ev1.record(one)
+    if not args.dry_run and strided and not args.no_single and not c["colour"]:
+        # ---- the literal "4096 frames/launch" of the configuration: one dispatch per batch, in order on the same stream, a hipGraph
+        #      replay of the whole rotation (the host out of the picture), HIP events on that stream ----
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(one):
+            for b in range(nbuf):
+                jsg.stft_db(plan, d_in[b], hop, F, d_out[b], stream=one.cuda_stream, **mixk)
             torch.cuda.synchronize()
-            inorder_us = ev0.elapsed_time(ev1) * 1e3 / (reps * lps)
-        if not c["colour"] and not args.no_graph:   # host-issued launches on the same stream, for comparison (adds the runtime's per-launch handling)
-            k = min(lps, 512)
-            with torch.cuda.stream(one):
-                for i in range(64):
-                    launch(i % nrot, one.cuda_stream)
-                torch.cuda.synchronize()
-                ev0.record(one)
-                for i in range(k):
-                    launch(i % nrot, one.cuda_stream)
-                ev1.record(one)
+            with torch.cuda.graph(g, stream=one):
+                for b in range(nbuf):
+                    jsg.stft_db(plan, d_in[b], hop, F, d_out[b], stream=one.cuda_stream, **mixk)
+            g.replay(); g.replay()
             torch.cuda.synchronize()
-            eager_us = ev0.elapsed_time(ev1) * 1e3 / k
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record(one)
+            for _ in range(8):
+                g.replay()
+            s1.record(one)
+        torch.cuda.synchronize()
+        single_us = s0.elapsed_time(s1) * 1e3 / (8 * nbuf)
     barrier(); sync()
     if dist is not None:
-        t = torch.tensor([wall, inorder_us or 0.0], dtype=torch.float64, device=red_dev)
+        t = torch.tensor([wall, dispatch_us or 0.0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, inorder_us = float(t[0]), (float(t[1]) or None)
+        wall, dispatch_us = float(t[0]), (float(t[1]) or None)
 
-    if rank == 0 and not args.dry_run and not args.no_graph:
-        # context for the roofline: a plain device-to-device copy of the SAME byte count, same rotation, same graph timing --
-        # what a launch of this size can reach at all on this GPU
-        nflt = algo // 8
-        csrc = [torch.rand(nflt, device="cuda") for _ in range(nrot)]
-        cdst = [torch.empty(nflt, device="cuda") for _ in range(nrot)]
-        g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(one):
-            cdst[0].copy_(csrc[0]); torch.cuda.synchronize()
-            with torch.cuda.graph(g2, stream=one):
-                for i in range(min(lps, 256)):
-                    cdst[i % nrot].copy_(csrc[i % nrot])
-            g2.replay(); torch.cuda.synchronize()
-            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            c0.record(one)
-            for _ in range(4):
-                g2.replay()
-            c1.record(one)
-        torch.cuda.synchronize()
-        copy_us = c0.elapsed_time(c1) * 1e3 / (4 * min(lps, 256))
-        del csrc, cdst, g2
+    if rank == 0 and not args.dry_run and world == 1 and not args.no_calibration:
+        calibration = calibrate_copy(lib, torch, one)
     if rank == 0 and not args.dry_run and world == 1 and not args.no_parity:
         parity = parity_report(jsg, c, plan, base, win)
-        if batch:   # the timed strided launch against one-by-one launches of the same images (same kernel plan), three images of the batch
-            with torch.cuda.stream(one):
-                launch(0, one.cuda_stream)
+        # the timed strided dispatch against one-by-one launches of the same batches (2048 / 4096 points: the same kernel plan)
+        with torch.cuda.stream(one):
+            if c["colour"]:
+                dispatch(one.cuda_stream)
                 tmp = torch.zeros((H, img_pitch), dtype=torch.int32, device="cuda")
                 differing = 0
-                for k in sorted({0, ipl // 2, ipl - 1}):
+                for k in sorted({0, nbuf // 2, nbuf - 1}):
                     tmp.zero_()
-                    jsg.stft_image(plan, d_in[k], hop, F, d_lut, -50.0, 50.0, tmp[:, :F], None, feedblocks=fb, mix_mode=jsg.capi.MIX_ABSMEAN,
-                                   plan_select=2, stream=one.cuda_stream)
-                    differing += int((tmp != d_img_all[k]).sum())
-            parity["strided_batch_pixels_differing_from_single_launches"] = differing
+                    jsg.stft_image(plan, d_in[k], hop, F, d_lut, -50.0, 50.0, tmp[:, :F], None, plan_select=2, stream=one.cuda_stream, **mixk)
+                    differing += int((tmp != d_img[k]).sum())
+                parity["strided_pixels_differing_from_single_launches"] = differing
+            elif strided:
+                d_out.fill_(-7.0)
+                dispatch(one.cuda_stream)
+                pin = 0 if n not in (2048, 4096) else (2 if "B," in kernel_label else 1)
+                tmp = torch.empty((F, pitch), dtype=torch.float32, device="cuda")
+                differing = 0
+                for k in sorted({0, nbuf // 2, nbuf - 1}):
+                    tmp.fill_(-7.0)
+                    jsg.stft_db(plan, d_in[k], hop, F, tmp, plan_select=pin, stream=one.cuda_stream, **mixk)
+                    differing += int((tmp != d_out[k]).sum())
+                parity["strided_columns_differing_from_single_launches"] = differing
+        torch.cuda.synchronize()
 
-    units_total = world * args.steps * lps * units_per_launch
-    gate_note = " (the gate is inside the timed region: this mode is for the tracer)"
-    if batch:
-        issue_text = ("strided batches of independent images, one kernel launch per batch (jsg_stft_image_launch_strided), "
-                      + ("host-issued" if args.no_graph else "hipGraph replay") + ", in order on one stream")
-    elif n_streams == 1:
-        issue_text = ("hipGraph replay, in order" if not args.no_graph else
-                      "host-issued behind a gate kernel, in order and back to back on one stream" + gate_note if args.gate else "host-issued, in order on one stream")
-    elif c["colour"]:
-        issue_text = f"{n_streams} hipGraphs per step (independent images, one stream each), replayed together"
-    else:
-        issue_text = ("one jsg_stft_db_launch_batches call per step on one caller stream: the library forks onto its own streams (4; 2 for the "
-                      "one-workgroup-per-CU kernels), issues from 2 host threads and joins" if (not args.streams and not args.gate) else
-                      f"one C call per step, {max(1, args.issue_threads)} host thread(s)")
-        if args.gate:
-            issue_text += ", every stream held by a gate kernel while the host enqueues the step" + gate_note
+    units_total = world * args.steps * dps * bpd * units_per_batch
+    algo = algo_batch * bpd                            # algorithmic bytes of one dispatch
+    unit_word = "columns" if c["colour"] or C > 1 else "frames"
     out = {
         "metric": c["metric"], "value": None if args.dry_run else units_total / wall, "unit": c["unit"],
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": c["workload"],
-                   "step": (f"{lps} launches x {ipl} images x {F} columns = {lps * units_per_launch} columns per step and GPU" if batch else
-                            f"{lps} launches x {F} {'columns' if c['colour'] or C > 1 else 'frames'} = {lps * units_per_launch} {c['unit'].split('/')[0]} per step and GPU"),
-                   "launches_per_step": lps, "images_per_launch": ipl if c["colour"] else None, "frames_per_launch": F * C * ipl, "columns_per_launch": F * ipl,
-                   "channels_per_gpu": C,
-                   "distinct_batches": nbuf, "hip_streams_per_gpu": n_streams, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
-                   "issue": issue_text,
+                   "step": f"{dps} dispatches x {bpd} {'images' if c['colour'] else 'batches'} x {F} {unit_word} = {dps * bpd * units_per_batch} {c['unit'].split('/')[0]} per step and GPU",
+                   "dispatches_per_step": dps, "batches_per_dispatch": bpd, "frames_per_batch": F * C, "columns_per_batch": F, "frames_per_dispatch": F * C * bpd,
+                   "channels_per_gpu": C, "distinct_batches": nbuf, "rotation_bytes": None if args.dry_run else int(nbuf * per_batch),
+                   "hip_streams_per_gpu": 1, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+                   "issue": (("jsg_stft_image_launch_strided" if c["colour"] else "jsg_stft_db_launch_strided") +
+                             f": K = {bpd} independent {'images' if c['colour'] else f'{F}-frame batches'} per kernel dispatch, the dispatches of a step back to back "
+                             "on ONE stream, issued by plain C calls (no hipGraph, no extra streams, no hardware-queue setting)") if strided else
+                            "one dispatch per batch, in order on one stream, host-issued",
                    "prewarm_s": round(prewarm_s, 3),
                    "parallelism": f"{world} GPU(s), independent batches, no data-path collective"},
     }
     if args.dry_run:
         out["dry_run"] = True
-    if inorder_us:
-        achieved = algo / (inorder_us * 1e-6) / 1e9
-        conc = algo * lps * args.steps / wall / 1e9
+    if dispatch_us:
+        achieved = algo / (dispatch_us * 1e-6) / 1e9
+        conc = algo * dps * args.steps / wall / 1e9
         # HBM traffic (PMC) and the tracer's per-dispatch duration come from the rocprofv3 passes of tools/profile_bench.sh
-        # (profiles/r03_<cfg>_hbm_traffic.json): bench.py does not run counters itself.  The file carries the hash of the kernel
-        # sources it was recorded with; when that differs from this build's the figures are flagged as stale and `frac` falls back
-        # to this run's own event timing.
+        # (profiles/r04_<cfg>_hbm_traffic.json): bench.py does not run counters itself.  The file carries the hash of the kernel sources
+        # it was recorded with; when that differs from this build's the figures are flagged as stale.
         traffic, tsrc, rocprof_us = None, None, None
-        prof = os.path.join(ROOT, "profiles", f"r03_{args.config}_hbm_traffic.json")
-        if os.path.exists(prof):
+        prof = os.path.join(ROOT, "profiles", f"r04_{args.config}_hbm_traffic.json")
+        if os.path.exists(prof) and strided:
             try:
                 pj = json.load(open(prof))
-                same = pj.get("kernel_source_sha") == kernel_source_sha() and int(pj.get("images_per_launch") or 1) == ipl
+                same = pj.get("kernel_source_sha") == kernel_source_sha() and int(pj.get("batches_per_dispatch") or 1) == bpd
                 traffic = pj.get("hbm_bytes_per_launch")
                 rocprof_us = pj.get("avg_us") if same else None
                 tsrc = {"file": os.path.relpath(prof, ROOT), "recorded_at_commit": pj.get("commit"), "kernel_source_sha": pj.get("kernel_source_sha"),
                         "matches_this_build": same, "rocprof_avg_dispatch_us": pj.get("avg_us"),
-                        "note": "rocprofv3 passes of tools/profile_bench.sh (kernel trace; FETCH_SIZE x2 on gfx950 + WRITE_SIZE in separate PMC passes), "
-                                "recorded earlier; NOT measured by this run" + ("" if same else " -- STALE: the kernel sources have changed since")}
+                        "note": "rocprofv3 passes of tools/profile_bench.sh over this same command (kernel trace; FETCH_SIZE x2 on gfx950 + WRITE_SIZE in separate "
+                                "PMC passes), recorded earlier; NOT measured by this run" + ("" if same else " -- STALE: the kernel sources have changed since")}
             except Exception:
                 traffic = None
-        frac_events = achieved / HBM_PEAK_GBS
-        frac_rocprof = (algo / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rocprof_us else None
+        frac = achieved / HBM_PEAK_GBS
         out["roofline"] = {
-            "bound": "hbm", "achieved": (frac_rocprof or frac_events) * HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": frac_rocprof or frac_events,
-            "frac_source": ("rocprofv3 per-dispatch average of the same in-order launches (profiles/, same kernel sources)" if frac_rocprof
-                            else "this run's HIP events (no matching rocprofv3 profile under profiles/)"),
-            "frac_event_timed": frac_events, "frac_rocprof": frac_rocprof,
-            "frac_of_8p0": frac_rocprof or frac_events, "frac_of_6p3": (frac_rocprof or frac_events) * HBM_PEAK_GBS / HBM_ACHIEVABLE_GBS,
-            "traffic": traffic, "traffic_source": tsrc,
-            "kernel": (kernel_label if c["colour"] else f"stft_db_kernel<{(parity or {}).get('kernel', n)}>"),
-            "avg_launch_us": inorder_us, "avg_launch_us_host_issued": eager_us,
-            "how": f"HIP events on the launch stream around {'host-issued runs' if args.no_graph else 'hipGraph replays'} of the step's {lps} launches, one at a time in order",
-            "algorithmic_bytes_per_launch": algo,
-            "timed_region_achieved": conc, "timed_region_frac_of_8p0": conc / HBM_PEAK_GBS, "timed_region_frac_of_6p3": conc / HBM_ACHIEVABLE_GBS,
-            "note": "achieved/frac: per-kernel view (in order, one stream); timed_region_*: algorithmic bytes of the K timed steps / their wall "
-                    "time (independent launches overlapped on hip_streams_per_gpu streams)",
-            "memcpy_same_bytes_us": copy_us, "frac_of_memcpy_rate": (copy_us / inorder_us) if copy_us else None,
-            "second_roof": valu_roof(c, units_per_launch, inorder_us),
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
+            "frac_source": "this run: algorithmic bytes per dispatch / average dispatch duration of the timed region (HIP events on the launch stream around the K steps)",
+            "avg_dispatch_us": dispatch_us, "algorithmic_bytes_per_dispatch": algo, "algorithmic_bytes_per_batch": algo_batch,
+            "timed_region_achieved": conc, "timed_region_frac": conc / HBM_PEAK_GBS,
+            "frac_rocprof": (algo / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rocprof_us else None,
+            "frac_of_measured_copy_roof": (achieved / calibration["peak_copy_GBps"]) if calibration else None,
+            "traffic": traffic, "traffic_source": tsrc, "kernel": kernel_label,
+            "second_roof": valu_roof(c, units_per_batch * bpd, dispatch_us),
             "commit": commit,
         }
+        if single_us:
+            out["roofline"]["one_batch_per_dispatch"] = {
+                "what": f"the same batches, ONE jsg_stft_db_launch per {F}-frame batch, in order on one stream (hipGraph replay of the rotation, HIP events)",
+                "avg_dispatch_us": single_us, "algorithmic_bytes_per_dispatch": algo_batch, "frac": algo_batch / (single_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "units_per_s": units_per_batch / (single_us * 1e-6)}
+    if calibration is not None:
+        out["calibration"] = calibration
     if parity is not None:
         out["parity"] = parity
-    if default_env is not None:
-        out["config"]["same_region_default_environment"] = default_env
+    if extra is not None:
+        out["extra"] = extra
     if boundary is not None and rank == 0:
         boundary["pcie_inclusive_rate"] = boundary_pcie_rate(jsg, c)
         out["boundary"] = boundary

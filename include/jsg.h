@@ -202,6 +202,11 @@ int jsg_stft_db_strided_kernel_name(const jsg_plan* plan, const jsg_stft_args* a
  * for partial sums that were reduced across GPUs (JSG_MIX_SUM).  In place (out == power) is allowed. */
 int jsg_db_from_power_launch(const float* power, float* out, int64_t count, float divisor, void* stream);
 
+/* Roofline calibration (no reference counterpart): a tuned float4 streaming copy of `bytes` bytes (multiple of 16, 16-byte aligned
+ * device pointers), non-temporal loads and stores, one thread per 16 bytes.  bench.py times it on buffers that rotate over > 1 GB to
+ * report what the HBM of THIS box gives a balanced read + write stream (`peak_copy_GBps`), the yardstick beside the 8 TB/s spec. */
+int jsg_calib_copy_launch(const void* src, void* dst, int64_t bytes, void* stream);
+
 /* Colour loop: dB ring columns -> ARGB pixels (and/or 8-bit palette indices).
  * Replaces the pixel loops of SpectrogramComponent::timerCallback (Spectrogram.cpp:632-648,
  * :673-680, :693-700) with CColorPalette::getRGBColor inlined (CColorpalette.h:32-47):

@@ -139,6 +139,15 @@ __global__ __launch_bounds__(256) void db_from_power_kernel(const float* p, floa
     }
 }
 
+// roofline calibration (jsg_calib_copy_launch): the float4 streaming copy that reaches the most on an MI355X -- one thread per 16 bytes,
+// non-looping grid (the dispatcher hands the workgroups out in address order: the access front stays tight), non-temporal loads and
+// stores (tools/copy_roof.hip: 6.4-6.5 TB/s read + written at >= 0.5 GB, 6.3 at 134 MB; grid-stride forms 4.5-6.3)
+__global__ __launch_bounds__(256) void calib_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n4) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const v4f*>(src) + i), reinterpret_cast<v4f*>(dst) + i);
+}
+
 }  // namespace jsg
 
 using namespace jsg;
@@ -820,6 +829,19 @@ int jsg_db_from_power_launch(const float* power, float* out, int64_t count, floa
                        reinterpret_cast<hipStream_t>(stream), power, out, (long long)count, divisor);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return jsg_fail_hip(err, "jsg_db_from_power_launch");
+    return JSG_OK;
+}
+
+int jsg_calib_copy_launch(const void* src, void* dst, int64_t bytes, void* stream) {
+    if (bytes == 0) return JSG_OK;
+    if (!src || !dst || bytes < 0 || (bytes & 15) || ((reinterpret_cast<unsigned long long>(src) | reinterpret_cast<unsigned long long>(dst)) & 15))
+        return jsg_fail(JSG_ERR_INVALID, "jsg_calib_copy_launch: needs 16-byte aligned pointers and a byte count that is a multiple of 16");
+    const long long n4 = bytes / 16, blocks = (n4 + 255) / 256;
+    if (blocks >= (1ll << 31)) return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_calib_copy_launch: more than 2^31 workgroups");
+    hipLaunchKernelGGL(calib_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), static_cast<const float*>(src),
+                       static_cast<float*>(dst), n4);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return jsg_fail_hip(err, "jsg_calib_copy_launch");
     return JSG_OK;
 }
 

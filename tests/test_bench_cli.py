@@ -38,8 +38,17 @@ def test_single_process_dry_run_prints_the_contract_fields():
     j = _run([sys.executable, "bench.py", "--dry-run", "--steps", "3", "--warmup", "1"])
     assert REQUIRED <= set(j) and j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["dry_run"] is True
     assert j["metric"] == "STFT frames/sec (1024-pt, 50% hop)" and j["unit"] == "frames/s" and j["scaling"] == "weak"
-    assert "4096 frames/launch" in j["config"]["workload"] and j["config"]["launches_per_step"] == 1024
+    assert "4096 frames/launch" in j["config"]["workload"] and j["config"]["dispatches_per_step"] == 16 and j["config"]["batches_per_dispatch"] == 64
+    assert "16 dispatches x 64 batches x 4096 frames" in j["config"]["step"] and j["config"]["hip_streams_per_gpu"] == 1
     assert j["value"] is None and j["vs_baseline"] is None and j["dtype"] == "f32"
+
+
+def test_bench_does_not_touch_the_hardware_queue_variable():
+    """Rounds 2-3 leaned on GPU_MAX_HW_QUEUES (set by bench.py and by a library constructor); the strided launch needs neither."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "GPU_MAX_HW_QUEUES\", \"" not in src and "setdefault(\"GPU_MAX" not in src and 'environ["GPU_MAX_HW_QUEUES"]' not in src
+    eng = open(os.path.join(ROOT, "jadespectrogram_amd", "csrc", "jsg_engine.cpp")).read()
+    assert "setenv(" not in eng.replace("setenv is not thread-safe", "")
 
 
 def test_two_ranks_dry_run_over_gloo():
@@ -49,54 +58,65 @@ def test_two_ranks_dry_run_over_gloo():
 
 @pytest.mark.gpu
 def test_two_ranks_share_one_gpu_and_run_the_kernels():
-    j = _run(_torchrun(2, ["--steps", "2", "--warmup", "1", "--launches-per-step", "64", "--no-cpu-baseline"]),
+    j = _run(_torchrun(2, ["--steps", "2", "--warmup", "1", "--dispatches-per-step", "2", "--nbuf", "8", "--no-cpu-baseline"]),
              env={"JSG_BENCH_BACKEND": "gloo"})
     assert REQUIRED <= set(j) and j["n_gpus"] == 2 and j["value"] > 1e7            # north_star's >= 1e7 frames/s, whole job
-    assert j["config"]["launches_per_step"] == 64 and j["roofline"]["avg_launch_us"] > 0
-    assert abs(j["ms_per_step"] * j["steps"] * 1e-3 * j["value"] - 2 * 2 * 64 * 4096) < 1.0   # value = all ranks' frames / timed wall
+    assert j["config"]["dispatches_per_step"] == 2 and j["config"]["batches_per_dispatch"] == 8 and j["roofline"]["avg_dispatch_us"] > 0
+    assert abs(j["ms_per_step"] * j["steps"] * 1e-3 * j["value"] - 2 * 2 * 2 * 8 * 4096) < 1.0   # value = all ranks' frames / timed wall
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg,unit", [("c3", "frames/s"), ("c5", "columns/s")])
 def test_other_configs_emit_a_line(cfg, unit):
-    j = _run([sys.executable, "bench.py", "--config", cfg, "--steps", "2", "--warmup", "1", "--launches-per-step", "8", "--no-cpu-baseline"])
-    assert j["unit"] == unit and j["value"] > 0 and j["roofline"]["algorithmic_bytes_per_launch"] > 0
+    j = _run([sys.executable, "bench.py", "--config", cfg, "--steps", "2", "--warmup", "1", "--dispatches-per-step", "2", "--no-cpu-baseline", "--no-calibration"])
+    k = j["config"]["batches_per_dispatch"]
+    assert j["unit"] == unit and j["value"] > 0 and k >= 8
     assert j["parity"]["max_rel_power_err_bins_within_20dB_of_peak"] < 1e-5
     assert j["parity"]["colour_index_flips_end_to_end"] <= max(4, j["parity"]["pixels_checked"] // 500)
-    if cfg == "c5":   # default: strided batches, one kernel launch for a whole rotation of images; the pixels are those of single launches
-        k = j["config"]["images_per_launch"]
-        assert k > 8 and "jsg_stft_image_launch_strided" in j["config"]["issue"] and j["config"]["launches_per_step"] == 8
-        assert j["roofline"]["algorithmic_bytes_per_launch"] == k * 1875 * 12292
-        assert j["parity"]["strided_batch_pixels_differing_from_single_launches"] == 0
-        assert abs(j["ms_per_step"] * j["steps"] * 1e-3 * j["value"] - 2 * 8 * k * 1875) < 1.0
+    if cfg == "c5":   # strided batches, one kernel launch for a whole rotation of images; the pixels are those of single launches
+        assert "jsg_stft_image_launch_strided" in j["config"]["issue"]
+        assert j["roofline"]["algorithmic_bytes_per_dispatch"] == k * 1875 * 12292
+        assert j["parity"]["strided_pixels_differing_from_single_launches"] == 0
+        assert abs(j["ms_per_step"] * j["steps"] * 1e-3 * j["value"] - 2 * 2 * k * 1875) < 1.0
+    else:
+        assert "jsg_stft_db_launch_strided" in j["config"]["issue"] and "Cfg2048B" in j["roofline"]["kernel"]
+        assert j["roofline"]["algorithmic_bytes_per_dispatch"] == k * 4096 * 20484
+        assert j["parity"]["strided_columns_differing_from_single_launches"] == 0
+        assert abs(j["ms_per_step"] * j["steps"] * 1e-3 * j["value"] - 2 * 2 * k * 4096 * 8) < 1.0
 
 
 @pytest.mark.gpu
-def test_c5_one_image_per_launch_mode_still_runs():
-    j = _run([sys.executable, "bench.py", "--config", "c5", "--images-per-launch", "1", "--steps", "2", "--warmup", "1", "--launches-per-step", "9",
-              "--no-cpu-baseline", "--no-boundary"])
-    assert j["config"]["images_per_launch"] == 1 and j["config"]["hip_streams_per_gpu"] == 3 and j["value"] > 0
-    assert j["roofline"]["algorithmic_bytes_per_launch"] == 1875 * 12292 and "strided_batch_pixels_differing_from_single_launches" not in j["parity"]
+def test_single_mode_one_dispatch_per_batch_still_runs():
+    j = _run([sys.executable, "bench.py", "--mode", "single", "--steps", "2", "--warmup", "1", "--dispatches-per-step", "32", "--no-cpu-baseline",
+              "--no-boundary", "--no-calibration", "--no-extra"])
+    assert j["config"]["batches_per_dispatch"] == 1 and j["value"] > 1e7 and j["roofline"]["algorithmic_bytes_per_dispatch"] == 4096 * 4100
 
 
 @pytest.mark.gpu
-def test_default_config_line_carries_roofline_boundary_and_default_environment():
-    """The driver's line (configs[1]) with few launches per step: the objects the contract asks for are there and consistent --
-    roofline (fraction, source, traffic with its staleness flag, the event-timed figure beside it), parity of the kernel that is
-    timed, the boundary block (producer latency under a reading consumer, PCIe-inclusive rate) and the same region in the
-    default environment (no extra hardware queues)."""
-    j = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--launches-per-step", "64", "--no-cpu-baseline"], timeout=900)
+def test_default_config_line_carries_roofline_calibration_boundary_and_the_other_configs():
+    """The driver's line (configs[1]) with few dispatches per step: the objects the contract asks for are there and consistent --
+    roofline measured live on the timed region (fraction, per-dispatch duration, the whole-region figure beside it, traffic with its
+    staleness flag, the one-batch-per-dispatch figure), the measured copy roof, parity of the kernel that is timed, the boundary block
+    (producer latency under a reading consumer, PCIe-inclusive rate), and the c3 / c5 results from their child processes."""
+    j = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--dispatches-per-step", "2", "--no-cpu-baseline"], timeout=1200)
     assert REQUIRED <= set(j) and j["n_gpus"] == 1 and j["value"] > 1e7 and j["scaling"] == "weak" and j["dtype"] == "f32"
     r = j["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert r["frac_event_timed"] > 0 and r["algorithmic_bytes_per_launch"] == 4096 * 4100
+    assert r["algorithmic_bytes_per_dispatch"] == 64 * 4096 * 4100 and r["algorithmic_bytes_per_batch"] == 4096 * 4100
+    assert abs(r["timed_region_frac"] / r["frac"] - 1.0) < 0.05          # one stream, back to back: the region IS its dispatches
     assert r["traffic_source"] is None or isinstance(r["traffic_source"]["matches_this_build"], bool)
     assert (r["frac_rocprof"] is not None) == bool(r["traffic_source"] and r["traffic_source"]["matches_this_build"])
-    assert r["second_roof"]["bound"] == "valu_issue"
+    assert r["second_roof"]["bound"] == "valu_issue" and "Cfg1024" in r["kernel"]
+    assert 0.2 < r["one_batch_per_dispatch"]["frac"] < r["frac"]
+    cal = j["calibration"]
+    assert 4000.0 < cal["peak_copy_GBps"] < 8000.0 and cal["sizes"]["8.4MB"]["GBps"] < cal["peak_copy_GBps"]
+    assert j["config"]["GPU_MAX_HW_QUEUES"] is None and "jsg_stft_db_launch_strided" in j["config"]["issue"]
     assert j["parity"]["kernel"] == "Cfg1024" and j["parity"]["fused_image_pixels_differing_from_two_kernel_image"] == 0
+    assert j["parity"]["strided_columns_differing_from_single_launches"] == 0
     b = j["boundary"]
     assert b["process_block_latency"]["ring_bit_identical_to_undisturbed_batch_run"] is True and b["process_block_latency"]["p50_us"] < 100.0
     assert b["pcie_inclusive_rate"]["host_memory"]["pinned"]["frames_per_s"] > 1e6
-    d = j["config"]["same_region_default_environment"]
-    assert d["value"] > 1e7 and "unset" in d["GPU_MAX_HW_QUEUES"]
-    assert "jsg_stft_db_launch_batches" in j["config"]["issue"]
+    for cfg, kern in (("c3", "Cfg2048B"), ("c5", "Cfg4096B")):
+        e = j["extra"][cfg]
+        assert "error" not in e, e
+        assert e["value"] > 1e6 and kern in e["kernel"] and 0.05 < e["roofline"]["frac"] < 1.0

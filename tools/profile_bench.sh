@@ -6,18 +6,16 @@
 #   3. one SQ counter pass
 # Summaries are post-processed by tools/profile_summarize.py into gpurun_out/profiles_<tag>/ (copy them to profiles/).
 set -u
-TAG=${1:-r03}; CFG=${2:-c2}
+TAG=${1:-r04}; CFG=${2:-c2}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_bench_${TAG}_${CFG}
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# --streams 1 --no-graph: the timed region is one launch at a time, host-issued (rocprofv3 neither traces nor counts kernels
-# inside hipGraph replays -- its counter passes crash on them), so the per-dispatch duration is the per-kernel number
-# that bench.py's `roofline` reports; the driver-shaped step counts are used as they are
-GATE=""; [ "$CFG" = c2 ] && GATE="--gate"     # short kernels: keep the traced dispatches back to back (bench.py --gate)
-CMD="python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --streams 1 --no-graph $GATE --steps 20 --warmup 5 --no-cpu-baseline --no-boundary --no-parity"
-# counter passes: the same launches, fewer of them (the collector serialises every dispatch, and crashed on the 25 000
-# queued dispatches of the full-size command); counters are per-dispatch means, so the count does not matter
-PMC_CMD="$CMD --launches-per-step 32 --steps 10 --warmup 2"
+# The timed region of bench.py IS a sequence of back-to-back dispatches of one kernel on one stream, host-issued by plain C calls: the
+# tracer sees exactly what the bench times.  The side legs (parity, calibration, one-batch-per-dispatch, child runs) are switched off so
+# that the trace holds the main kernel only; otherwise this is the driver's command.
+CMD="python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --steps 20 --warmup 5 --no-cpu-baseline --no-boundary --no-parity --no-extra --no-calibration --no-single"
+# counter passes: the same dispatches, fewer of them (the collector serialises every dispatch); counters are per-dispatch means
+PMC_CMD="python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --steps 3 --warmup 1 --dispatches-per-step 2 --no-cpu-baseline --no-boundary --no-parity --no-extra --no-calibration --no-single"
 echo "$CMD" > $OUT/command.txt
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1 || echo "stats pass failed"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $PMC_CMD > $OUT/fetch.log 2>&1 || echo "fetch pass failed"

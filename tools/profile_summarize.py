@@ -17,12 +17,13 @@ res["kernel_source_sha"] = bench.kernel_source_sha()   # bench.py trusts these f
 # the bench line printed under the tracer (its in-order number must agree with the tracer's average)
 try:
     line = json.loads(open(os.path.join(out_dir, "bench_lines.jsonl")).readline())
-    res["bench_line_under_trace"] = {"value": line["value"], "unit": line["unit"], "avg_launch_us": line["roofline"]["avg_launch_us"],
-                                     "frac_of_8p0": line["roofline"]["frac_of_8p0"]}
-    ipl = int(line["config"].get("images_per_launch") or 1)       # c5: images of one strided launch (one dispatch)
+    res["bench_line_under_trace"] = {"value": line["value"], "unit": line["unit"], "avg_dispatch_us": line["roofline"]["avg_dispatch_us"],
+                                     "frac": line["roofline"]["frac"], "timed_region_frac": line["roofline"]["timed_region_frac"],
+                                     "dispatches_timed": line["steps"] * line["config"]["dispatches_per_step"]}
+    ipl = int(line["config"].get("batches_per_dispatch") or 1)       # batches (c5: images) of one strided dispatch
 except Exception:
     ipl = 1
-res["images_per_launch"] = ipl
+res["batches_per_dispatch"] = ipl
 # 1. kernel stats
 main_kernel = "stft_db_kernel"
 for f in glob.glob(os.path.join(out_dir, "stats", "**", "*kernel_stats.csv"), recursive=True):
@@ -62,7 +63,7 @@ if fetch and write:
     res["fetch_bytes_corrected"] = fetch * 1024 * 2
     res["write_bytes"] = write * 1024
     res["hbm_bytes_per_launch"] = res["fetch_bytes_corrected"] + res["write_bytes"]
-    res["algorithmic_bytes_per_launch"] = bench.algorithmic_bytes_per_launch(bench.CONFIGS[cfg]) * ipl
+    res["algorithmic_bytes_per_launch"] = bench.algorithmic_bytes_per_batch(bench.CONFIGS[cfg]) * ipl
     res["traffic_over_algorithmic"] = res["hbm_bytes_per_launch"] / res["algorithmic_bytes_per_launch"]
     if "avg_us" in res:
         res["frac_of_8p0_from_trace_avg"] = res["algorithmic_bytes_per_launch"] / (res["avg_us"] * 1e-6) / 8e12
@@ -83,7 +84,7 @@ for kname, d in res["counters_mean_per_dispatch"].items():
                                                                               ("waiting_to_issue_lds", "SQ_WAIT_INST_LDS")) if v in d},
            "lds_bank_conflict_share_of_lds_cycles": (d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]) if d.get("SQ_LDS_IDX_ACTIVE") else None,
            "lds_array_cycles_per_fft": d.get("SQ_LDS_IDX_ACTIVE", 0.0) / ffts,
-           "note": "issuing_valu x (waves per SIMD: 4 at C2, 2 at C3 / C5) = share of the time a SIMD's vector pipe is issuing"}
+           "note": "issuing_valu x (waves per SIMD: 6 at C2, 2 at C3 / C5) = share of the time a SIMD's vector pipe is issuing"}
     res.setdefault("derived", {})[kname] = der
 json.dump(res, open(os.path.join(dst, f"{tag}_{cfg}_hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
