@@ -145,7 +145,12 @@ typedef struct jsg_stft_args {
                                 the last bits (both inside the parity bound): callers that cut one stream into launches of
                                 very different sizes and need bit-identical columns pin one of them (the engine pins 1).
                                 jsg_stft_kernel_name() tells which one a launch takes.  Other sizes: ignored */
-    int32_t reserved;        /* 0 */
+    int32_t exact_log;       /* 0: 10*log10 on the hardware log unit (1 ulp, not specified bit for bit); 1: by the library's own float32
+                                routine (jadespectrogram_amd/csrc/jsg_exact_math.h: exponent + degree-9 polynomial, within 2 ulp of the
+                                reference's double log10): every dB value -- and so every palette index -- is then reproducible bit for
+                                bit on a CPU (oracle/jsg_mirror.c does).  The launch stores linear power and converts its columns in
+                                place with a second, elementwise kernel (one more read + write of the output); the dB launches only
+                                (jsg_stft_db_launch, _strided, _batches, the engine via jsg_set_exact_log).  (was: reserved) */
 } jsg_stft_args;
 int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* args, void* stream);
 /* The kernel configuration jsg_stft_db_launch picks for these arguments on the current device, as text ("Cfg1024", "Cfg2048",
@@ -201,6 +206,8 @@ int jsg_stft_db_strided_kernel_name(const jsg_plan* plan, const jsg_stft_args* a
 /* out[i] = 10*log10(power[i]/divisor + 1e-11f), i < count: the tail of the mix (reference Spectrogram.cpp:74,107)
  * for partial sums that were reduced across GPUs (JSG_MIX_SUM).  In place (out == power) is allowed. */
 int jsg_db_from_power_launch(const float* power, float* out, int64_t count, float divisor, void* stream);
+/* ... with the logarithm of jsg_stft_args.exact_log (1) instead of the hardware unit (0) */
+int jsg_db_from_power_launch_ex(const float* power, float* out, int64_t count, float divisor, int exact_log, void* stream);
 
 /* Roofline calibration (no reference counterpart): a tuned float4 streaming copy of `bytes` bytes (multiple of 16, 16-byte aligned
  * device pointers), non-temporal loads and stores, one thread per 16 bytes.  bench.py times it on buffers that rotate over > 1 GB to
@@ -301,6 +308,8 @@ int jsg_set_window(jsg_engine* e, int window);                   /* Spectrogram.
 int jsg_set_window_table(jsg_engine* e, const float* w, int n);  /* extension: caller-supplied window */
 int jsg_set_mix_mode(jsg_engine* e, int mode);                   /* m_mode has no setter in the reference (:21) */
 int jsg_set_power_scale(jsg_engine* e, float scale);             /* normalisation of spectrum::power, default 1 */
+int jsg_set_exact_log(jsg_engine* e, int on);                    /* extension: jsg_stft_args.exact_log for the engine's launches (default 0);
+                                                                    keeps the ring (no buildmem) */
 
 int jsg_get_spectrum_size(const jsg_engine* e);                  /* Spectrogram.h:127 */
 int jsg_get_memory_size(const jsg_engine* e);                    /* Spectrogram.h:128 */

@@ -39,7 +39,7 @@ class StftArgs(C.Structure):
                 ("n_frames", C.c_int64), ("out_db", C.c_void_p), ("out_pitch", C.c_int64),
                 ("out_channel_pitch", C.c_int64), ("ring_width", C.c_int32), ("ring_pos", C.c_int32),
                 ("linear_out", C.c_int32), ("blocks_per_cu", C.c_int32), ("in_samples", C.c_int64),
-                ("plan_select", C.c_int32), ("reserved", C.c_int32)]
+                ("plan_select", C.c_int32), ("exact_log", C.c_int32)]
 
 
 class ColormapArgs(C.Structure):
@@ -82,6 +82,7 @@ SIGNATURES = {
     "jsg_stft_image_launch_strided": (C.c_int, [_P, C.POINTER(StftImageArgs), C.c_int, C.c_int64, C.c_int64, _P]),
     "jsg_stft_image_strided_needs_scratch": (C.c_int, [_P, C.POINTER(StftImageArgs), C.c_int]),
     "jsg_db_from_power_launch": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
+    "jsg_db_from_power_launch_ex": (C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_int, _P]),
     "jsg_create": (C.c_int, [C.POINTER(_P), C.c_int]),
     "jsg_create_on_device": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int]),
     "jsg_get_device": (C.c_int, [_P]),
@@ -102,6 +103,7 @@ SIGNATURES = {
     "jsg_set_window_table": (C.c_int, [_P, _P, C.c_int]),
     "jsg_set_mix_mode": (C.c_int, [_P, C.c_int]),
     "jsg_set_power_scale": (C.c_int, [_P, C.c_float]),
+    "jsg_set_exact_log": (C.c_int, [_P, C.c_int]),
     "jsg_get_spectrum_size": (C.c_int, [_P]),
     "jsg_get_memory_size": (C.c_int, [_P]),
     "jsg_get_samplerate": (C.c_float, [_P]),

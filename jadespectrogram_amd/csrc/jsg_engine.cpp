@@ -100,6 +100,7 @@ struct jsg_engine {
     bool window_custom = false;
     bool pause = false;
     float power_scale = 1.f;
+    int exact_log = 0;       // jsg_set_exact_log: dB by the shared float32 routine (bit-reproducible on a CPU) instead of v_log_f32
     std::vector<float> window;
 
     // derived geometry; the atomics mirror W, H, n and the channel count for the lock-free getters
@@ -311,6 +312,7 @@ int run_blocks(jsg_engine* e, int blocks) {
         a.ring_width = e->W;
         a.ring_pos = int((e->mem_counter + skip) % e->W);
         a.plan_select = 1;   // the ring must not depend on how the host cut the stream into calls: always the same kernel
+        a.exact_log = e->exact_log;
         const int rc = jsg_stft_db_launch(e->plan, &a, e->stream);
         if (rc != JSG_OK) return e->fail_tls(rc);
         e->mem_counter = int((e->mem_counter + frames) % e->W);
@@ -590,6 +592,12 @@ int jsg_set_power_scale(jsg_engine* e, float scale) {
     e->power_scale = scale;
     JSG_HIP(e, hipStreamSynchronize(e->stream));
     return rebuild_plan(e);
+}
+
+int jsg_set_exact_log(jsg_engine* e, int on) {
+    JSG_LOCK_CONFIG(e);
+    e->exact_log = on ? 1 : 0;   // (columns already in the ring keep the logarithm they were written with)
+    return JSG_OK;
 }
 
 // lock-free getters (the GUI polls them while the audio thread runs)

@@ -130,13 +130,27 @@ __global__ __launch_bounds__(256) void colormap_kernel(const CmapKArgs a) {
 }
 
 __global__ __launch_bounds__(256) void db_from_power_kernel(const float* p, float* out,
-                                                            long long count, float divisor) {
+                                                            long long count, float divisor, int exact_log) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
         float v = p[i];
         if (divisor != 1.0f) v = v / divisor;
-        out[i] = to_db(v);
+        out[i] = exact_log ? jsg_exact_db(v) : to_db(v);
     }
+}
+
+// jsg_stft_args.exact_log: the columns a launch has just written as LINEAR mixed power become dB in place through jsg_exact_db (plain
+// float32 arithmetic shared with the CPU mirror, jsg_exact_math.h).  A separate elementwise pass on purpose: as a run-time branch
+// inside stft_db_kernel it moved the register allocation of every instantiation (three VGPRs more, spills in the index-out forms of
+// the 1024- and 4096-point plans), and the default path -- the hardware log unit -- must not pay for an opt-in mode.
+// grid (columns, rows): column i of the launch = ring column (ring_pos + i) % ring_w of row y (a batch, or a batch x channel plane)
+__global__ __launch_bounds__(256) void exact_db_columns_kernel(float* base, long long col_pitch, int height, int ring_w, int ring_pos,
+                                                               long long row_stride_a, int rows_a, long long row_stride_b) {
+    unsigned col = (unsigned)ring_pos + blockIdx.x;
+    if (col >= (unsigned)ring_w) col -= ring_w;
+    const unsigned ya = blockIdx.y % (unsigned)rows_a, yb = blockIdx.y / (unsigned)rows_a;   // (channel plane, batch)
+    float* p = base + (long long)ya * row_stride_a + (long long)yb * row_stride_b + (long long)col * col_pitch;
+    for (int k = threadIdx.x; k < height; k += 256) p[k] = jsg_exact_db(p[k]);
 }
 
 // roofline calibration (jsg_calib_copy_launch): the float4 streaming copy that reaches the most on an MI355X -- one thread per 16 bytes,
@@ -345,6 +359,25 @@ struct BatchSpec {   // jsg_stft_db_launch_strided: `n` batches of the geometry 
 static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const IndexOut* io, void* stream, const BatchSpec* bs = nullptr) {
     if (!plan || !g) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: null argument");
     if (g->n_frames == 0) return JSG_OK;
+    if (g->exact_log && !g->linear_out) {
+        // bit-reproducible dB: the kernel stores the mixed LINEAR power (the very float its own logarithm would have taken), then the
+        // columns of the launch are turned into dB in place by the shared float32 routine (exact_db_columns_kernel)
+        if (io) return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_image_launch: exact_log is a mode of the dB launches (jsg_stft_db_launch + jsg_colormap_launch)");
+        jsg_stft_args lin = *g;
+        lin.linear_out = 1;
+        lin.exact_log = 0;
+        const int rc = stft_launch_impl(plan, &lin, nullptr, stream, bs);
+        if (rc != JSG_OK) return rc;
+        const int planes = g->mix_mode == JSG_MIX_PER_CHANNEL ? g->channels : 1;
+        const long long rows = (long long)planes * (bs ? bs->n : 1);
+        if (rows > 65535) return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_db_launch: exact_log with more than 65535 channel planes x batches in one launch");
+        hipLaunchKernelGGL(exact_db_columns_kernel, dim3((unsigned)g->n_frames, (unsigned)rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g->out_db,
+                           (long long)g->out_pitch, plan->n / 2 + 1, g->ring_width, g->ring_pos, (long long)g->out_channel_pitch, planes,
+                           bs ? bs->out_stride : 0ll);
+        const hipError_t err = hipGetLastError();
+        if (err != hipSuccess) return jsg_fail_hip(err, "jsg_stft_db_launch (exact_log pass)");
+        return JSG_OK;
+    }
     const int H = plan->n / 2 + 1;
     if (!g->in || (!io && !g->out_db) || g->channels <= 0 || g->hop <= 0 || g->feedblocks <= 0 || g->n_frames < 0 ||
         g->first_frame < 0 || g->ring_width <= 0 || g->ring_pos < 0 || g->ring_pos >= g->ring_width ||
@@ -822,11 +855,15 @@ int jsg_stft_db_launch_batches(const jsg_plan* plan, const jsg_stft_args* args, 
 }
 
 int jsg_db_from_power_launch(const float* power, float* out, int64_t count, float divisor, void* stream) {
+    return jsg_db_from_power_launch_ex(power, out, count, divisor, 0, stream);
+}
+
+int jsg_db_from_power_launch_ex(const float* power, float* out, int64_t count, float divisor, int exact_log, void* stream) {
     if (count == 0) return JSG_OK;
     if (!power || !out || count < 0 || !(divisor > 0.f)) return jsg_fail(JSG_ERR_INVALID, "jsg_db_from_power_launch: bad argument");
     const long long blocks = (count + 255) / 256;
     hipLaunchKernelGGL(db_from_power_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), power, out, (long long)count, divisor);
+                       reinterpret_cast<hipStream_t>(stream), power, out, (long long)count, divisor, exact_log ? 1 : 0);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return jsg_fail_hip(err, "jsg_db_from_power_launch");
     return JSG_OK;

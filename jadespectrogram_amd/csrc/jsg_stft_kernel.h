@@ -40,6 +40,7 @@
 
 #include "../../include/jsg.h"
 #include "jsg_internal.h"
+#include "jsg_exact_math.h"
 
 namespace jsg {
 
@@ -174,6 +175,36 @@ __device__ __forceinline__ void dft(cf (&x)[R]) {
             x[2 * q] = a[q];
             x[2 * q + 1] = b[q];
         }
+    }
+}
+
+// The first radix stage with the window multiply folded into its first butterfly layer: that layer forms lo + hi and lo - hi of two
+// WINDOWED samples; the upper one's product is taken on its own (one packed multiply), the lower one's is fused into the add and the
+// subtract (one packed fma each) -- a = fma(x_lo, w_lo, P_hi), d = fma(x_lo, w_lo, -P_hi) -- which saves P/2 packed multiplies per frame.
+// (The optimiser contracted the separate statements into exactly this form before; it is written out so that the rounding is a property
+// of the source, not of an optimisation: oracle/jsg_mirror.c restates it, tests/test_gpu_mirror.py holds the two together bit for bit.)
+// x[J], J < R/2: raw samples with their window values w[J]; x[J + R/2]: already multiplied by their window values.
+template <int R, int J>
+struct DifLayerWin {
+    static __device__ __forceinline__ void run(const cf (&x)[R], const cf (&w)[R / 2], cf (&a)[R / 2], cf (&b)[R / 2]) {
+        const cf hi = x[J + R / 2];
+        a[J] = __builtin_elementwise_fma(x[J], w[J], hi);
+        const cf d = __builtin_elementwise_fma(x[J], w[J], -hi);
+        b[J] = mul_w_q1<J % (R / 4), R>(d);
+        if constexpr (J + 1 < R / 2) DifLayerWin<R, J + 1>::run(x, w, a, b);
+    }
+};
+template <int R>
+__device__ __forceinline__ void dft_win(cf (&x)[R], const cf (&w)[R / 2]) {
+    static_assert(R >= 4, "radix");
+    cf a[R / 2], b[R / 2];
+    DifLayerWin<R, 0>::run(x, w, a, b);
+    dft<R / 2, false>(a);
+    dft<R / 2, true>(b);
+#pragma unroll
+    for (int q = 0; q < R / 2; ++q) {
+        x[2 * q] = a[q];
+        x[2 * q + 1] = b[q];
     }
 }
 
@@ -705,16 +736,25 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                 for (int m = 0; m < P; ++m) { raw[f][m].x = __int_as_float(0x3f800000 + lane + m + s + f); raw[f][m].y = 0.5f; }
         }
         JSG_MARK(0);
-        // ---- window multiply ----
+        // ---- window multiply: register m = u + U1 n1 is input n1 of stage-1 butterfly u.  The upper inputs (n1 >= R1 / 2) are multiplied
+        //      here; the lower ones stay raw and keep their window values, their products are fused into the butterfly (dft_win) ----
+        cf wlo[P / 2];   // window values of the lower inputs, index (m % U1) + U1 * n1 == m for m < P / 2
 #pragma unroll
         for (int m = 0; m < P; m += 2) {
             cf w0, w1;
             tab2(C::TAB_WIN, m, w0, w1);
+            static_assert((P / 2) % 2 == 0 || P == 2, "the window pairs do not straddle the halves");
 #pragma unroll
             for (int f = 0; f < F; ++f) {
-                x[f][m] = to_cf(raw[f][m]) * w0;
-                x[f][m + 1] = to_cf(raw[f][m + 1]) * w1;
+                if (m < P / 2) {     // (m < P/2 <=> n1 < R1/2: P/2 = U1 * R1/2)
+                    x[f][m] = to_cf(raw[f][m]);
+                    x[f][m + 1] = to_cf(raw[f][m + 1]);
+                } else {
+                    x[f][m] = to_cf(raw[f][m]) * w0;
+                    x[f][m + 1] = to_cf(raw[f][m + 1]) * w1;
+                }
             }
+            if (m < P / 2) { wlo[m] = w0; wlo[m + 1] = w1; }
         }
         if constexpr (C::ABL == 3) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -747,7 +787,10 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
             for (int f = 0; f < F; ++f) {
 #pragma unroll
                 for (int n1 = 0; n1 < R1; ++n1) t[f][n1] = x[f][u + U1 * n1];
-                dft<R1>(t[f]);
+                cf wl[R1 / 2];
+#pragma unroll
+                for (int n1 = 0; n1 < R1 / 2; ++n1) wl[n1] = wlo[u + U1 * n1];
+                dft_win<R1>(t[f], wl);
                 lds0[f * C::LDS_ELEMS + ll + L * u] = t[f][0];
             }
 #pragma unroll
@@ -913,7 +956,9 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                         z.x = __int_as_float(sub ? bx : ax);
                         z.y = __int_as_float(sub ? by : ay);
                     }
-                    accNy[f] = mix_combine<MIXOP>(accNy[f], 4.0f * (z.x * z.x + z.y * z.y));
+                    // (the fused form is written out: which of the two products the compiler contracts is its choice otherwise, and
+                    // oracle/jsg_mirror.c restates this kernel operation by operation)
+                    accNy[f] = mix_combine<MIXOP>(accNy[f], 4.0f * __builtin_fmaf(z.x, z.x, z.y * z.y));
                 }
             }
         }

@@ -90,6 +90,7 @@ class Spectrogram:
     def setWindow(self, win): self._c(lib().jsg_set_window(self._h, int(win)))
     def setMixMode(self, mode): self._c(lib().jsg_set_mix_mode(self._h, int(mode)))
     def setPowerScale(self, s): self._c(lib().jsg_set_power_scale(self._h, s))
+    def setExactLog(self, on): self._c(lib().jsg_set_exact_log(self._h, int(bool(on))))
 
     def setWindowTable(self, w):
         w = np.ascontiguousarray(w, dtype=np.float32)
@@ -262,12 +263,12 @@ class StftLaunch:
 
 def stft_db(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: int | None = None, mix_mode: int = 0,
             first_frame: int = 0, ring_pos: int = 0, linear_out: bool = False, blocks_per_cu: int = 0,
-            stream: int | None = None, plan_select: int = 0):
+            stream: int | None = None, plan_select: int = 0, exact_log: bool = False):
     """Enqueue one fused STFT->dB launch.  d_in: torch CUDA float32 [C][samples]; d_out: [W][pitch] (or
     [C][W][pitch] with mix_mode PER_CHANNEL).  Frame j starts at sample (j//feedblocks)*n + (j%feedblocks)*hop."""
     import torch
     a = _stft_args(plan, d_in, hop, n_frames, d_out, feedblocks=feedblocks, mix_mode=mix_mode, first_frame=first_frame,
-                   ring_pos=ring_pos, linear_out=linear_out, blocks_per_cu=blocks_per_cu, plan_select=plan_select)
+                   ring_pos=ring_pos, linear_out=linear_out, blocks_per_cu=blocks_per_cu, plan_select=plan_select, exact_log=exact_log)
     if stream is None:
         stream = torch.cuda.current_stream(d_in.device).cuda_stream
     check(lib().jsg_stft_db_launch(plan._p, C.byref(a), C.c_void_p(stream)))
@@ -319,7 +320,8 @@ def stft_kernel_name(plan: Plan, d_in, hop: int, n_frames: int, d_out, **kw) -> 
 
 
 def _stft_args(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: int | None = None, mix_mode: int = 0,
-               first_frame: int = 0, ring_pos: int = 0, linear_out: bool = False, blocks_per_cu: int = 0, plan_select: int = 0):
+               first_frame: int = 0, ring_pos: int = 0, linear_out: bool = False, blocks_per_cu: int = 0, plan_select: int = 0,
+               exact_log: bool = False):
     import torch
     assert d_in.is_cuda and d_in.dtype == torch.float32 and d_in.dim() == 2 and d_in.stride(1) == 1
     assert d_out.is_cuda and d_out.dtype == torch.float32 and d_out.stride(-1) == 1
@@ -345,6 +347,7 @@ def _stft_args(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: 
     a.ring_pos = ring_pos
     a.linear_out = int(bool(linear_out))
     a.blocks_per_cu = int(blocks_per_cu)
+    a.exact_log = int(bool(exact_log))     # dB by the shared float32 routine (bit-reproducible on a CPU) instead of v_log_f32
     a.plan_select = int(plan_select)       # 0 automatic, 1 small-workgroup kernel, 2 "B" kernel (2048 / 4096 points)
     return a
 
@@ -379,7 +382,7 @@ def colormap(d_db, d_lut, lo: float, hi: float, *, d_argb=None, d_index=None, co
 
 def _stft_image_args(plan: Plan, d_in, hop: int, n_frames: int, d_lut, lo: float, hi: float, d_argb, d_index_scratch, *,
                      feedblocks: int | None = None, mix_mode: int = 0, first_frame: int = 0, ring_pos: int = 0,
-                     ring_width: int | None = None, x_first: int | None = None, plan_select: int = 0):
+                     ring_width: int | None = None, x_first: int | None = None, plan_select: int = 0, exact_log: bool = False):
     import torch
     assert d_argb.is_cuda and d_argb.element_size() == 4 and d_argb.dim() == 2 and d_argb.stride(1) == 1
     if d_index_scratch is not None:
@@ -400,6 +403,7 @@ def _stft_image_args(plan: Plan, d_in, hop: int, n_frames: int, d_lut, lo: float
     st.ring_width = W
     st.ring_pos = ring_pos
     st.plan_select = int(plan_select)
+    st.exact_log = int(bool(exact_log))
     a.stft = st
     c = capi.ColormapArgs()
     c.ring_width = W

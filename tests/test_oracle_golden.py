@@ -170,3 +170,37 @@ def test_c_port_agrees_with_numpy_oracle(oracle):
         assert got.shape == ref.shape
         assert (got[0] == np.float32(-110.0)).all()
         assert np.abs(got - ref).max() < 2e-3 and np.median(np.abs(got - ref)) < 1e-5
+
+
+# ---- the kernel mirror (oracle/jsg_mirror.c): the bit-exactness checker of the GPU path is itself held to the float64 oracle ----
+def test_mirror_of_the_gpu_arithmetic_is_within_the_parity_bound_of_the_float64_dft(oracle):
+    from oracle import mirror as mirror_mod
+    from parity_util import assert_power_close
+    m = mirror_mod.load()
+    for n, plans in mirror_mod.PLANS.items():
+        for hop, C, win_kind in ((n // 2, 1, oracle.WIN_HANN), (n // 4, 3, oracle.WIN_BLACKMANHARRIS)):
+            F = 12
+            x = oracle.synth_audio(C, (F - 1) * hop + n, seed=n + C)
+            win = oracle.window(win_kind, n)
+            idx = (np.arange(F) * hop)[:, None] + np.arange(n)[None, :]
+            frames = (x[:, idx] * win[None, None, :]).astype(np.float32)
+            ref = oracle.mix_channels(oracle.power_spectrum_f64(frames).astype(np.float32), oracle.MIX_ABSMEAN).astype(np.float64)
+            for plan in plans:
+                got = m.columns(plan, x, hop, F, win, feedblocks=n // hop, mix=oracle.MIX_ABSMEAN)
+                assert_power_close(got, ref, f"mirror {plan} C={C}")
+
+
+def test_shared_exact_logarithm_is_within_two_ulp_of_the_reference_expression():
+    """jsg_exact_db (csrc/jsg_exact_math.h, compiled into the mirror and into the GPU's exact_log pass) against the reference's
+    float(10.0 * log10(double(p + 1e-11f))) (Spectrogram.cpp:107): at most 2 ulp of the dB value, 4.1e-6 dB absolute."""
+    from oracle import mirror as mirror_mod
+    m = mirror_mod.load()
+    rng = np.random.default_rng(7)
+    p = np.concatenate([10.0 ** rng.uniform(-14, 12, 400000), rng.uniform(0, 2, 100000), [0.0, 1e-11, 1.0, 0.99999994, 2.0, 1e-30]]).astype(np.float32)
+    got = m.exact_db(p)
+    y = (p + np.float32(1e-11)).astype(np.float32)
+    ref64 = 10.0 * np.log10(y.astype(np.float64))
+    ref = ref64.astype(np.float32)
+    ulp = np.abs(got.astype(np.float64) - ref.astype(np.float64)) / np.spacing(np.abs(ref)).astype(np.float64)
+    assert ulp.max() <= 2.0 and np.abs(got.astype(np.float64) - ref64).max() < 5e-6
+    assert got[p == 0.0][0] == np.float32(10.0 * np.log10(np.float64(np.float32(1e-11))))      # the -110 dB of an all-zero frame
