@@ -197,12 +197,13 @@ def boundary_latency_subprocess():
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
                                os.path.join(ROOT, "tests", "cpp", "producer_latency_test.cpp"), "-o", exe, "-L", libdir, "-ljsg",
                                f"-Wl,-rpath,{libdir}", "-lpthread"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        r = subprocess.run([exe, "400", "300"], capture_output=True, text=True, timeout=120)
+        r = subprocess.run([exe, "20000", "250", "256"], capture_output=True, text=True, timeout=180)
         info = json.loads(r.stdout.strip().splitlines()[-1])
-        return {"call": "jsg_process_block (host planar pointers in, enqueue only), one 4096-sample stereo block per call, 400 calls, 300 us apart",
+        return {"call": "jsg_process_block (wait-free: lock-free ring of page-locked memory, the engine's worker thread makes the HIP calls), one 4096-sample "
+                        "stereo block per call, 20 000 calls, 250 us apart",
                 "under": f"a consumer thread alternating jsg_get_mem and jsg_display_update on the 1875 x 2049 ring without pause ({info['reads']} reads meanwhile)",
-                "p50_us": info["p50_us"], "p99_us": info["p99_us"], "max_us_after_first_call": info["max_after_first_us"],
-                "first_call_us": info["first_call_us"],
+                "p50_us": info["p50_us"], "p99_us": info["p99_us"], "p9999_us": info["p9999_us"], "max_us_after_first_call": info["max_after_first_us"],
+                "first_call_us": info["first_call_us"], "calls_over_50us": info["calls_over_50us"], "dropped_blocks": info["dropped_blocks"],
                 "ring_bit_identical_to_undisturbed_batch_run": info["differing_floats"] == 0 and info["differing_pixels"] == 0}
     except Exception as e:   # a reported figure, never a reason to lose the bench line
         return {"error": f"{type(e).__name__}: {e}"[:200]}

@@ -15,10 +15,11 @@
  *   - nothing throws across this boundary; jsg_last_error() gives the text of the last failure.
  *   - an engine is bound to the HIP device that is current when it is created; one engine per GPU,
  *     one process per GPU for multi-GPU use (channels/streams are sharded, no collective needed).
- *   - threading: one producer thread (process_*) and one consumer thread (get_mem / display_* / setters).
- *     jsg_process_block never waits for the consumer: readers take their snapshot of the ring on a second HIP
- *     stream and hold the state lock only while they enqueue; what follows them waits on the GPU, not on the
- *     audio thread.  Setters quiesce the engine (the reference's m_protect around setFFTSize, Spectrogram.cpp:162).
+ *   - threading: one producer thread (jsg_process_block) and one consumer thread (get_mem / display_* / setters).
+ *     jsg_process_block is wait-free (a lock-free ring of page-locked memory; a worker thread of the engine makes the HIP
+ *     calls); readers take their snapshot of the ring on a second HIP stream and hold the state lock only while they
+ *     enqueue; what follows them waits on the GPU.  Setters quiesce the engine (the reference's m_protect around
+ *     setFFTSize, Spectrogram.cpp:162).
  *   - there is NO CPU fallback: every compute entry point fails with JSG_ERR_HIP / JSG_ERR_NO_DEVICE
  *     when no gfx950 device is usable.
  */
@@ -320,9 +321,19 @@ int jsg_get_feedblocks(const jsg_engine* e);
 int jsg_get_channels(const jsg_engine* e);
 int jsg_get_window(const jsg_engine* e, float* out, int n);      /* copy of m_window */
 
-/* Spectrogram::processSynchronBlock (Spectrogram.cpp:37-135): `planar` = channels host pointers to
- * fft-size samples each.  Enqueues H2D copy + one kernel launch; returns without waiting. */
+/* Spectrogram::processSynchronBlock (Spectrogram.cpp:37-135): `planar` = channels host pointers to fft-size samples each.
+ * WAIT-FREE on the caller's (audio) thread: the block is copied into a page-locked single-producer ring and published with one
+ * atomic store; a worker thread owned by the engine does the H2D copy and the launch.  No mutex, no HIP call, no allocation, never
+ * a wait: when the ring is full (the GPU more than 64 blocks behind) or the engine is in the middle of a channel-count / FFT-size
+ * change the block is DROPPED and counted.  Returns 0 (queued), 1 (dropped), < 0 (error -- also an error the worker thread met
+ * earlier, text in jsg_last_error).  Readers, setters and jsg_sync see every block whose call returned before theirs began. */
 int jsg_process_block(jsg_engine* e, const float* const* planar);
+/* The same for callers that state the geometry their pointers were sized for (host classes whose re-blocker runs unlocked beside
+ * the FFT-size combo box): a block of another channel count or length than the engine's current one is dropped (returns 1)
+ * instead of being read past its end.  0 = do not check that value. */
+int jsg_process_block_n(jsg_engine* e, const float* const* planar, int channels, int n);
+/* blocks dropped by jsg_process_block(_n) since the engine was created */
+long long jsg_get_dropped_blocks(const jsg_engine* e);
 /* The same for n_blocks consecutive blocks in one launch: samples[c*pitch + i], i < n_blocks*n. */
 int jsg_process_blocks(jsg_engine* e, const float* samples, int64_t pitch, int n_blocks);
 /* The same with the samples already in HBM (device pointer, same layout); no host copy. */

@@ -12,7 +12,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libjsg.so")
 
 SOURCES = ["jsg_kernels.hip", "jsg_stft_a.hip", "jsg_stft_b.hip", "jsg_engine.cpp", "jsg_host_math.cpp"]
-HEADERS = ["jsg_internal.h", "jsg_stft_kernel.h", "jsg_colormap_tables.inc", os.path.join(ROOT, "include", "jsg.h")]
+HEADERS = ["jsg_internal.h", "jsg_block_queue.h", "jsg_exact_math.h", "jsg_stft_kernel.h", "jsg_colormap_tables.inc", os.path.join(ROOT, "include", "jsg.h")]
 # device-compile flags of every .hip unit:
 #   -fno-slp-vectorize: the kernel packs its complex arithmetic into v_pk_*_f32 by hand (re, im in one register pair); the automatic
 #       SLP pass pairs unrelated scalars and pays ~140 register moves per FFT

@@ -113,6 +113,8 @@ SIGNATURES = {
     "jsg_get_channels": (C.c_int, [_P]),
     "jsg_get_window": (C.c_int, [_P, _P, C.c_int]),
     "jsg_process_block": (C.c_int, [_P, C.POINTER(_P)]),
+    "jsg_process_block_n": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int]),
+    "jsg_get_dropped_blocks": (C.c_longlong, [_P]),
     "jsg_process_blocks": (C.c_int, [_P, _P, C.c_int64, C.c_int]),
     "jsg_process_blocks_device": (C.c_int, [_P, _P, C.c_int64, C.c_int]),
     "jsg_get_mem": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),

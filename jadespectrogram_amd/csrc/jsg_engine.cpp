@@ -14,7 +14,7 @@
 //                                  padded to 32 pixels: with 128-byte-aligned rows the 64-pixel tiles of a full
 //                                  recolour write whole cache lines (C5 image: 8.2 instead of 10.2 us).
 //   d_lut   [n_colors] int32       CColorPalette table.
-//   h_pin   (host, page-locked)    8 slots of [channels][n] floats: staging ring of processSynchronBlock.
+//   h_q     (host, page-locked)    64 slots of [channels][n] floats: the audio thread's block queue (see "Producer" below).
 //   h_mem   (host, page-locked)    [planes][W][H] floats: landing area of getMem's device-to-host copies.
 //
 // Threads (reference: audio thread = producer, message thread = consumer and setters):
@@ -27,22 +27,37 @@
 //   rstream read-out stream: copies of ring columns, colour kernel, image copies.  A reader records an event on
 //           `stream`, lets `rstream` wait for it (so it sees every column produced before the call), enqueues its ring
 //           reads, and makes `stream` wait for the event behind those reads: later kernels start after the snapshot
-//           was taken -- a dependency on the GPU, not on the audio thread.  jsg_process_block therefore never waits
-//           for a reader: its worst case is the mutex hand-over of an enqueue section (microseconds).
+//           was taken -- a dependency on the GPU, not on the audio thread.
+//
+// Producer (round 4; reference call path PluginProcessor.cpp:145-150 -> Spectrogram::processSynchronBlock, Spectrogram.cpp:37-48):
+//   jsg_process_block is WAIT-FREE: it copies the block into a slot of a single-producer / single-consumer ring of page-locked
+//   memory and publishes it with one atomic store -- no mutex, no HIP call, no system call, no allocation, never a wait.  A worker
+//   thread that the engine owns takes the blocks out in order and does every HIP call (H2D copy, launch) under `mu`, exactly
+//   what the audio thread did itself until round 3.  A full ring (the GPU more than 64 blocks behind) or an engine in the
+//   middle of a geometry change DROPS the block and counts it (return value 1, jsg_get_dropped_blocks) instead of blocking.
+//   Geometry changes (channel count, FFT size: the slot size changes) use an epoch instead of a lock on the producer's side:
+//   cfg_gen goes odd, the setter waits until the one producer call that may be in flight has left (prod_inflight), drains the
+//   queue, rebuilds, and makes cfg_gen even again; a producer that sees an odd value drops its block (history is wiped by that
+//   setter anyway, reference buildmem, Spectrogram.cpp:213-238).  Readers, the other setters, jsg_sync and the batch entry
+//   points first wait until the worker has taken every block that was pushed before they were called (flush_queue): a block whose
+//   jsg_process_block has returned is part of everything that is read afterwards, as before.
 //
 // There is no CPU compute path here: without a usable HIP device every entry point reports an error.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
+#include "jsg_block_queue.h"
 #include "jsg_internal.h"
 
 // (Rounds 2-3 had a library constructor here that set GPU_MAX_HW_QUEUES for the process.  It is gone: a plugin is loaded into a
@@ -120,13 +135,13 @@ struct jsg_engine {
     long long new_entry = kNewEntrySentinel;
     unsigned long long generation = 0;   // bumped by every reconfiguration (buildmem)
 
-    // pinned staging ring of processSynchronBlock (audio thread): the block is copied into page-locked memory and
-    // leaves for the GPU with an asynchronous DMA, so the caller never waits for the device
-    static const int kPinSlots = 8;
-    float* h_pin = nullptr;
-    size_t pin_slot_floats = 0;
-    hipEvent_t pin_done[kPinSlots] = {};
-    unsigned pin_next = 0;
+    // the audio thread's block queue (jsg_process_block; jsg_block_queue.h): single producer, single consumer = the worker thread.
+    // Its slots live in page-locked memory that the geometry setters (and creation) allocate: 64 x [channels][n] floats.
+    BlockQueue q;
+    std::atomic<int> async_rc{0};                  // first error the worker met (text in `err`); reported by the calls that follow
+    hipEvent_t ev_q = nullptr;                     // "the H2D copy has read the slot"
+    std::thread worker;
+    std::atomic<bool> stop{false};
 
     // getMem (readers only, under rd_mu): d_snap takes a device-side copy of the wanted ring columns (microseconds; the
     // only part later kernels have to wait for), h_mem is the page-locked landing area of the slow copy across PCIe
@@ -260,16 +275,19 @@ int buildmem(jsg_engine* e) {
     e->in_cap_blocks = 0;
     rc = ensure_input_capacity(e, 1, false);
     if (rc != JSG_OK) return rc;
+    // the producer's queue: only the geometry setters (and creation) come here with a changed slot size; they have made sure that
+    // no producer call is inside and that the worker has drained the queue (GeomEpoch)
     const size_t slot = size_t(e->channels) * size_t(e->n);
-    if (slot != e->pin_slot_floats) {
-        if (e->h_pin) (void)hipHostFree(e->h_pin);
-        e->h_pin = nullptr;
-        e->pin_slot_floats = 0;
-        JSG_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_pin), slot * jsg_engine::kPinSlots * sizeof(float), hipHostMallocDefault));
-        e->pin_slot_floats = slot;
+    if (slot != e->q.slot_floats) {
+        if (e->q.mem) (void)hipHostFree(e->q.mem);
+        e->q.mem = nullptr;
+        e->q.slot_floats = 0;
+        JSG_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->q.mem), slot * BlockQueue::kSlots * sizeof(float), hipHostMallocDefault));
+        e->q.slot_floats = slot;
     }
-    for (int i = 0; i < jsg_engine::kPinSlots; ++i)
-        if (!e->pin_done[i]) JSG_HIP(e, hipEventCreateWithFlags(&e->pin_done[i], hipEventDisableTiming));
+    e->q.channels = e->channels;
+    e->q.n = e->n;
+    if (!e->ev_q) JSG_HIP(e, hipEventCreateWithFlags(&e->ev_q, hipEventDisableTiming));
     e->mem_counter = 0;
     e->new_entry = kNewEntrySentinel;
     e->host_fixed_valid = false;
@@ -338,6 +356,66 @@ int reader_end(jsg_engine* e) {
     return JSG_OK;
 }
 
+// ---- the worker thread: takes the audio thread's blocks out of the queue in order and does what processSynchronBlock does ----
+void drain_queue(jsg_engine* e) {
+    unsigned long long t;
+    const float* block;
+    bool current;
+    while (e->q.front(t, block, current)) {
+        bool copied = false;
+        {
+            std::lock_guard<std::mutex> lk(e->mu);
+            // a block that was pushed under another geometry than the current one is discarded (cannot happen while the geometry
+            // setters drain the queue before they rebuild; kept as a guard)
+            if (current && e->async_rc.load(std::memory_order_relaxed) == 0) {
+                int rc = JSG_OK;
+                hipError_t herr = hipMemcpy2DAsync(e->d_in + e->n, size_t(e->in_pitch) * 4, block, size_t(e->n) * 4, size_t(e->n) * 4,
+                                                   size_t(e->channels), hipMemcpyHostToDevice, e->stream);
+                if (herr == hipSuccess) herr = hipEventRecord(e->ev_q, e->stream);
+                if (herr != hipSuccess) rc = e->fail_hip(herr, "worker: H2D copy of a block");
+                else {
+                    copied = true;
+                    rc = run_blocks(e, 1);
+                }
+                if (rc != JSG_OK) e->async_rc.store(rc, std::memory_order_release);
+            }
+        }
+        if (copied) (void)hipEventSynchronize(e->ev_q);   // the DMA has read the slot (outside the state lock)
+        e->q.pop(t);
+    }
+}
+
+// The worker POLLS the queue instead of being woken by the producer: a wake-up (sem_post / futex) is a system call on the audio thread,
+// and the scheduler may run the woken thread in the caller's place.  250 us between polls while blocks keep coming (a block of the
+// plugin lasts 5-90 ms), 1 ms after 10 ms of silence: about a thousand short wake-ups per second and engine when idle.
+void worker_main(jsg_engine* e) {
+    (void)hipSetDevice(e->device);
+    int idle = 0;
+    while (!e->stop.load(std::memory_order_acquire)) {
+        unsigned long long t;
+        const float* block;
+        bool current;
+        if (e->q.front(t, block, current)) {
+            drain_queue(e);
+            idle = 0;
+        } else {
+            std::this_thread::sleep_for(std::chrono::microseconds(idle < 40 ? 250 : 1000));
+            if (idle < 1000000) ++idle;
+        }
+    }
+}
+
+// Every block whose jsg_process_block returned before this call is on the stream afterwards.  Never called with mu or rd_mu held
+// (the worker needs mu), and never from the audio thread.
+void flush_queue(jsg_engine* e) { e->q.wait_drained(); }
+
+// Geometry setters (channel count, FFT size): see "Producer" in the header comment.  Constructed BEFORE the setter takes its locks.
+struct GeomEpoch {
+    jsg_engine* e;
+    explicit GeomEpoch(jsg_engine* eng) : e(eng) { if (e) e->q.begin_geometry_change(); }
+    ~GeomEpoch() { if (e) e->q.end_geometry_change(); }
+};
+
 int create_on(jsg_engine** out, int channels, int device) {
     if (!out || channels <= 0) return jsg_fail(JSG_ERR_INVALID, "jsg_create: bad argument");
     *out = nullptr;
@@ -371,6 +449,13 @@ int create_on(jsg_engine** out, int channels, int device) {
         rc = buildmem(e);
         if (rc == JSG_OK) rc = build_window(e);   // (the reference leaves m_window empty until setFFTSize/setWindow)
         if (rc == JSG_OK) rc = upload_lut(e);
+    }
+    if (rc == JSG_OK) {
+        try {
+            e->worker = std::thread(worker_main, e);
+        } catch (...) {
+            rc = e->fail(JSG_ERR_NOMEM, "jsg_create: the worker thread could not be started");
+        }
     }
     if (rc != JSG_OK) {
         tls_error() = e->err;
@@ -451,6 +536,10 @@ int jsg_destroy_sharded(jsg_engine** engines, int n_devices) {
 
 int jsg_destroy(jsg_engine* e) {
     if (!e) return JSG_OK;
+    if (e->worker.joinable()) {
+        e->stop.store(true, std::memory_order_release);
+        e->worker.join();
+    }
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->rstream) (void)hipStreamSynchronize(e->rstream);
@@ -459,12 +548,11 @@ int jsg_destroy(jsg_engine* e) {
     if (e->d_in) (void)hipFree(e->d_in);
     if (e->d_lut) (void)hipFree(e->d_lut);
     if (e->d_img) (void)hipFree(e->d_img);
-    if (e->h_pin) (void)hipHostFree(e->h_pin);
+    if (e->q.mem) (void)hipHostFree(e->q.mem);
     if (e->h_mem) (void)hipHostFree(e->h_mem);
     if (e->d_snap) (void)hipFree(e->d_snap);
     if (e->ev_host) (void)hipEventDestroy(e->ev_host);
-    for (int i = 0; i < jsg_engine::kPinSlots; ++i)
-        if (e->pin_done[i]) (void)hipEventDestroy(e->pin_done[i]);
+    if (e->ev_q) (void)hipEventDestroy(e->ev_q);
     if (e->ev_ring) (void)hipEventDestroy(e->ev_ring);
     if (e->ev_read) (void)hipEventDestroy(e->ev_read);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -476,6 +564,7 @@ int jsg_destroy(jsg_engine* e) {
 // producer / short sections: the state lock only
 #define JSG_LOCK(e)                                                          \
     if (!(e)) return jsg_fail(JSG_ERR_INVALID, "null engine");               \
+    flush_queue(e);                                                          \
     std::lock_guard<std::mutex> _lk((e)->mu);                                \
     do {                                                                     \
         hipError_t _e = hipSetDevice((e)->device);                           \
@@ -485,6 +574,7 @@ int jsg_destroy(jsg_engine* e) {
 // setters: exclude the readers as well (they may free what a reader is still copying from)
 #define JSG_LOCK_CONFIG(e)                                                   \
     if (!(e)) return jsg_fail(JSG_ERR_INVALID, "null engine");               \
+    flush_queue(e);                                                          \
     std::lock_guard<std::mutex> _rlk((e)->rd_mu);                            \
     std::lock_guard<std::mutex> _lk((e)->mu);                                \
     do {                                                                     \
@@ -500,6 +590,7 @@ int jsg_set_samplerate(jsg_engine* e, float fs) {
 }
 
 int jsg_set_channels(jsg_engine* e, int channels) {
+    GeomEpoch epoch(e);
     JSG_LOCK_CONFIG(e);
     if (channels <= 0) return e->fail(JSG_ERR_INVALID, "channel count must be positive");
     e->channels = channels;
@@ -507,6 +598,7 @@ int jsg_set_channels(jsg_engine* e, int channels) {
 }
 
 int jsg_set_fft_size(jsg_engine* e, int n) {
+    GeomEpoch epoch(e);
     JSG_LOCK_CONFIG(e);
     if (n != 512 && n != 1024 && n != 2048 && n != 4096 && n != 8192)
         return e->fail(JSG_ERR_UNSUPPORTED, "FFT size must be 512, 1024, 2048, 4096 or 8192");
@@ -618,37 +710,25 @@ int jsg_get_window(const jsg_engine* ce, float* out, int n) {
     return JSG_OK;
 }
 
-int jsg_process_block(jsg_engine* e, const float* const* planar) {
+// Spectrogram::processSynchronBlock (reference Spectrogram.cpp:37-48: the copy-in; the frame loop runs on the worker thread).
+// WAIT-FREE on the caller's thread: two atomic read-modify-writes, channels x memcpy into page-locked memory, one atomic store; no
+// system call (the worker polls).  channels / n (> 0): the geometry the caller's pointers were sized for; a block that does not fit the engine's current
+// geometry is dropped (a host class whose FFT-size combo box has just been moved, reference Spectrogram.cpp:760-767).
+// Returns 0 (queued), 1 (dropped: ring full, geometry change in progress, or geometry mismatch), < 0 (error; also an error the worker
+// thread met earlier).
+int jsg_process_block_n(jsg_engine* e, const float* const* planar, int channels, int n) {
     if (!e) return jsg_fail(JSG_ERR_INVALID, "null engine");
     if (!planar) return e->fail(JSG_ERR_INVALID, "null block");
-    for (;;) {
-        std::unique_lock<std::mutex> lk(e->mu);
-        hipError_t herr = hipSetDevice(e->device);
-        if (herr != hipSuccess) return e->fail_hip(herr, "hipSetDevice");
-        // copy-in (reference Spectrogram.cpp:41-48) through the pinned ring: host memcpy now, DMA later
-        const unsigned slot = e->pin_next % jsg_engine::kPinSlots;
-        if (hipEventQuery(e->pin_done[slot]) != hipSuccess) {
-            // the GPU is 8 blocks behind: wait for the slot WITHOUT the lock, then start over (a setter may have run)
-            hipEvent_t ev = e->pin_done[slot];
-            const unsigned long long gen = e->generation;
-            lk.unlock();
-            herr = hipEventSynchronize(ev);
-            if (herr != hipSuccess) return e->fail_hip(herr, "hipEventSynchronize");
-            (void)gen;
-            continue;
-        }
-        ++e->pin_next;
-        float* stage = e->h_pin + size_t(slot) * e->pin_slot_floats;
-        for (int c = 0; c < e->channels; ++c) {
-            if (!planar[c]) return e->fail(JSG_ERR_INVALID, "null channel pointer");
-            std::memcpy(stage + size_t(c) * e->n, planar[c], size_t(e->n) * sizeof(float));
-        }
-        JSG_HIP(e, hipMemcpy2DAsync(e->d_in + e->n, size_t(e->in_pitch) * 4, stage, size_t(e->n) * 4, size_t(e->n) * 4,
-                                    size_t(e->channels), hipMemcpyHostToDevice, e->stream));
-        JSG_HIP(e, hipEventRecord(e->pin_done[slot], e->stream));
-        return run_blocks(e, 1);
-    }
+    const int arc = e->async_rc.load(std::memory_order_acquire);
+    if (arc != 0) return arc;
+    const int rc = e->q.push(planar, channels, n);
+    if (rc < 0) return e->fail(JSG_ERR_INVALID, "null channel pointer");
+    return rc;
 }
+
+int jsg_process_block(jsg_engine* e, const float* const* planar) { return jsg_process_block_n(e, planar, 0, 0); }
+
+long long jsg_get_dropped_blocks(const jsg_engine* e) { return e ? (long long)e->q.dropped.load(std::memory_order_relaxed) : JSG_ERR_INVALID; }
 
 int jsg_process_blocks(jsg_engine* e, const float* samples, int64_t pitch, int n_blocks) {
     JSG_LOCK(e);
@@ -679,6 +759,7 @@ namespace {
 // dst_dense: [planes*W][H] floats, or rows: planes*W pointers to H floats each (vector<vector<float>> of the host class).
 int get_mem_impl(jsg_engine* e, float* dst_dense, float* const* rows, int dst_columns, int* pos, bool peek = false) {
     if (!e) return jsg_fail(JSG_ERR_INVALID, "null engine");
+    flush_queue(e);   // every block pushed before this call is on the stream
     std::lock_guard<std::mutex> rlk(e->rd_mu);
     // Geometry cannot change while rd_mu is held (every setter takes it first), so the reader's own buffers are
     // (re)allocated here, OUTSIDE the state lock: page-locking 15 MB takes milliseconds and must not stall the producer.
@@ -793,6 +874,9 @@ int jsg_ring_device(jsg_engine* e, float** d_ring, int64_t* pitch, int* width, i
 
 int jsg_sync(jsg_engine* e) {
     if (!e) return jsg_fail(JSG_ERR_INVALID, "null engine");
+    flush_queue(e);
+    const int arc = e->async_rc.load(std::memory_order_acquire);
+    if (arc != 0) return arc;
     hipError_t herr = hipSetDevice(e->device);
     if (herr == hipSuccess) herr = hipStreamSynchronize(e->stream);   // no lock: the stream handle lives as long as the engine
     if (herr != hipSuccess) return e->fail_hip(herr, "jsg_sync");
@@ -911,6 +995,7 @@ hipError_t copy_cols(jsg_engine* e, uint32_t* argb, int64_t pitch, int x0, int f
 int jsg_display_update(jsg_engine* e, float min_color, float max_color, uint32_t* argb, int64_t pitch, int* new_vals,
                        int* pos_out) {
     if (!e) return jsg_fail(JSG_ERR_INVALID, "null engine");
+    flush_queue(e);
     std::lock_guard<std::mutex> rlk(e->rd_mu);
     if (!argb || pitch < e->a_W.load()) return e->fail(JSG_ERR_INVALID, "bad image buffer");
     Tick t;
@@ -972,6 +1057,7 @@ int jsg_display_update(jsg_engine* e, float min_color, float max_color, uint32_t
 int jsg_display_update_tile(jsg_engine* e, float min_color, float max_color, uint32_t* tile, int64_t tile_pitch,
                             int max_cols, int* new_vals, int* pos_out) {
     if (!e) return jsg_fail(JSG_ERR_INVALID, "null engine");
+    flush_queue(e);
     std::lock_guard<std::mutex> rlk(e->rd_mu);
     if (!tile || max_cols <= 0 || tile_pitch < max_cols) return e->fail(JSG_ERR_INVALID, "bad tile buffer");
     Tick t;

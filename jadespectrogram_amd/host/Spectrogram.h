@@ -43,21 +43,21 @@ public:
         const int rc = jsg_create(&e, 2);   // m_channels(2), Spectrogram.cpp:17
         if (rc != JSG_OK) throw std::runtime_error(std::string("Spectrogram: ") + jsg_last_error(nullptr));
         m_engine.reset(e);
+        m_ptrs.resize(64);   // (grown by setchannels for wider buses)
         setDesiredBlockSizeSamples(size_t(jsg_get_fft_size(e)));
     }
 
     virtual int processSynchronBlock(std::vector<std::vector<float>>& data, juce::MidiBuffer& midiMessages) override {
         juce::ignoreUnused(midiMessages);
-        const size_t ch = size_t(jsg_get_channels(m_engine.get()));
-        const size_t n = size_t(jsg_get_fft_size(m_engine.get()));
-        if (data.size() < ch) return JSG_ERR_SIZE_MISMATCH;
-        m_ptrs.resize(ch);
-        for (size_t c = 0; c < ch; ++c) {
-            if (data[c].size() < n) return JSG_ERR_SIZE_MISMATCH;
-            m_ptrs[c] = data[c].data();
-        }
-        return jsg_process_block(m_engine.get(), m_ptrs.data());
+        // Wait-free: the block goes into the engine's lock-free ring together with the geometry it was sized for; the engine drops it
+        // (returns 1) when that is not its current geometry -- the FFT-size combo box has just been moved and the re-blocker has not
+        // been resized yet (setFFTSize below), or the ring is full -- instead of reading past the rows.
+        const size_t ch = data.size();
+        if (ch == 0 || ch > m_ptrs.size()) return JSG_ERR_SIZE_MISMATCH;   // (m_ptrs is sized on the message thread: channelsPrepared)
+        for (size_t c = 0; c < ch; ++c) m_ptrs[c] = data[c].data();
+        return jsg_process_block_n(m_engine.get(), m_ptrs.data(), int(ch), int(data[0].size()));
     }
+    long long droppedBlocks() const { return jsg_get_dropped_blocks(m_engine.get()); }   // blocks the engine did not take (see above)
     // Spectrogram::prepareParameter (reference Spectrogram.cpp:25-35): remember where the four display parameters live.
     // Nothing on the GPU depends on them; the IDs and defaults are those of reference Spectrogram.h:22-58
     // (frequencies are log-Hz, colour limits g_minColorVal / g_maxColorVal = -50 / +50 dB, PlugInGUISettings.h:37-38).
@@ -86,15 +86,15 @@ public:
     // setter
     void setSamplerate(float samplerate) { check(jsg_set_samplerate(m_engine.get(), samplerate)); }
     void setchannels(size_t newchannels) {
-        // under the re-blocker's lock, like setFFTSize: processSynchronBlock sizes its pointer table from the engine's channel
-        // count, so the count must not change between that read and jsg_process_block's use of the table
-        std::lock_guard<std::recursive_mutex> lk(syncLock());
+        std::lock_guard<std::recursive_mutex> lk(configLock());
+        // the pointer table grows on the message thread while the audio thread is kept out; the audio thread never allocates
+        if (m_ptrs.size() < newchannels) whileAudioThreadIsOut([&] { m_ptrs.resize(newchannels); });
         check(jsg_set_channels(m_engine.get(), int(newchannels)));
     }
     void setFFTSize(size_t newFFTSize) {
-        // engine size and re-blocker size change together under the re-blocker's lock (the reference's m_protect,
-        // Spectrogram.cpp:162-167): the audio thread can never hand a block of the old size to the new engine
-        std::lock_guard<std::recursive_mutex> lk(syncLock());
+        // engine first, re-blocker second (the reference does both under m_protect, Spectrogram.cpp:162-167).  In between the audio
+        // thread may still deliver blocks of the old size: they carry their size and the engine drops them.
+        std::lock_guard<std::recursive_mutex> lk(configLock());
         if (check(jsg_set_fft_size(m_engine.get(), int(newFFTSize)))) setDesiredBlockSizeSamples(newFFTSize);
     }
     void setclosestFFTSize_ms(float fftsize_ms) { setFFTSize(getnextpowerof2(fftsize_ms)); }

@@ -1,4 +1,6 @@
-// Audio-thread latency of jsg_process_block while a GUI thread reads as hard as it can (C-ABI, GPU box).
+// Audio-thread latency of jsg_process_block (wait-free since round 4: a lock-free ring + a worker thread of the engine) while a GUI
+// thread reads as hard as it can (C-ABI, GPU box).
+//   usage: producer_latency_test [blocks = 300] [pace_us = 500] [period = 256]      (the signal repeats after `period` blocks)
 //   C5 geometry: stereo 96 kHz, 4096-point FFT, hop 512 (87.5 % overlap), 10 s memory -> ring 1875 x 2049, 15 MB image.
 // The producer pushes `blocks` fft-size blocks at a real-time-like pace and records how long every call takes; a consumer
 // thread alternates jsg_get_mem (up to 15 MB device-to-host) and jsg_display_update (colour kernel + 15 MB image copy)
@@ -36,19 +38,20 @@ static int configure(jsg_engine* e) {
 int main(int argc, char** argv) {
     const int blocks = argc > 1 ? std::atoi(argv[1]) : 300;
     const int pace_us = argc > 2 ? std::atoi(argv[2]) : 500;   // pause between blocks (a 4096-sample block at 96 kHz lasts 42.7 ms)
+    const int period = std::max(1, std::min(blocks, argc > 3 ? std::atoi(argv[3]) : 256));
     const int C = 2, N = 4096;
     jsg_engine *live = nullptr, *batch = nullptr;
     CK(jsg_create(&live, C));
     CK(jsg_create(&batch, C));
     if (configure(live) || configure(batch)) return 2;
     const int W = jsg_get_memory_size(live), H = jsg_get_spectrum_size(live);
-    std::vector<float> x(size_t(C) * size_t(blocks) * N);
+    std::vector<float> x(size_t(C) * size_t(period) * N);
     unsigned s = 777u;
     for (size_t i = 0; i < x.size(); ++i) {
         s = s * 1664525u + 1013904223u;
         x[i] = 0.4f * std::sin(0.01f * float(i % 9973)) + 0.2f * (float(int(s >> 9)) / 4194304.0f - 1.0f);
     }
-    const size_t chan_pitch = size_t(blocks) * N;   // planar: channel c at x[c*chan_pitch ...]
+    const size_t chan_pitch = size_t(period) * N;   // planar: channel c at x[c*chan_pitch ...]
 
     std::atomic<bool> stop{false};
     std::atomic<long> reads{0}, read_columns{0};
@@ -70,7 +73,7 @@ int main(int argc, char** argv) {
     std::vector<double> lat;
     lat.reserve(size_t(blocks));
     for (int b = 0; b < blocks; ++b) {
-        const float* ptrs[2] = {x.data() + size_t(b) * N, x.data() + chan_pitch + size_t(b) * N};
+        const float* ptrs[2] = {x.data() + size_t(b % period) * N, x.data() + chan_pitch + size_t(b % period) * N};
         const auto t0 = std::chrono::steady_clock::now();
         const int rc = jsg_process_block(live, ptrs);
         const auto t1 = std::chrono::steady_clock::now();
@@ -83,8 +86,9 @@ int main(int argc, char** argv) {
     if (reader_rc.load() < 0) { std::fprintf(stderr, "reader failed: %s\n", jsg_last_error(live)); return 2; }
     CK(jsg_sync(live));
 
-    // reference run: the same samples, one batch, nobody reading
-    CK(jsg_process_blocks(batch, x.data(), int64_t(chan_pitch), blocks));
+    const long long dropped = jsg_get_dropped_blocks(live);
+    // reference run: the same samples in batches of one period, nobody reading
+    for (int b = 0; b < blocks; b += period) CK(jsg_process_blocks(batch, x.data(), int64_t(chan_pitch), std::min(period, blocks - b)));
     // both rings, column for column, without touching the new-column counters
     std::vector<float> a(size_t(W) * H), r(size_t(W) * H);
     int pa = -1, pr = -1;
@@ -107,9 +111,12 @@ int main(int argc, char** argv) {
     const double max_after_first = lat.size() > 1 ? *std::max_element(lat.begin() + 1, lat.end()) : 0.0;
     std::sort(lat.begin(), lat.end());
     auto pct = [&](double q) { return lat[size_t(q * double(lat.size() - 1))]; };
-    std::printf("{\"blocks\": %d, \"W\": %d, \"H\": %d, \"reads\": %ld, \"p50_us\": %.1f, \"p99_us\": %.1f, \"max_us\": %.1f, \"first_call_us\": %.1f, \"max_after_first_us\": %.1f, \"worst_call\": %zu, "
+    size_t over50 = 0;
+    for (double v : lat) over50 += v > 50.0;
+    std::printf("{\"blocks\": %d, \"W\": %d, \"H\": %d, \"reads\": %ld, \"p50_us\": %.2f, \"p99_us\": %.2f, \"p9999_us\": %.2f, \"max_us\": %.1f, \"first_call_us\": %.1f, "
+                "\"max_after_first_us\": %.1f, \"worst_call\": %zu, \"calls_over_50us\": %zu, \"dropped_blocks\": %lld, "
                 "\"pos_live\": %d, \"pos_batch\": %d, \"differing_floats\": %zu, \"differing_pixels\": %zu}\n",
-                blocks, W, H, reads.load(), pct(0.5), pct(0.99), lat.back(), first_us, max_after_first, worst_at, pa, pr, diff_floats, diff_px);
+                blocks, W, H, reads.load(), pct(0.5), pct(0.99), pct(0.9999), lat.back(), first_us, max_after_first, worst_at, over50, dropped, pa, pr, diff_floats, diff_px);
     jsg_destroy(live);
     jsg_destroy(batch);
     return 0;
