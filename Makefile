@@ -5,14 +5,12 @@ ARCH  ?= gfx950
 SRC   := jadespectrogram_amd/csrc
 OUT   := jadespectrogram_amd/libjsg.so
 OBJ   := jadespectrogram_amd/build
-# make DEV=1: also compile the development variants of the kernels (tools/sweep_variants.sh, tools/stamps.py)
-DEVFLAG := $(if $(filter 1,$(DEV)),-DJSG_DEV_VARIANTS,)
 
 .PHONY: lib oracle test-cpp clean
 lib: $(OUT)
 
-HIPFLAGS := -std=c++17 -O3 -fPIC -Iinclude --offload-arch=$(ARCH) -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=16 $(DEVFLAG)
-KDEPS    := $(SRC)/jsg_stft_kernel.h $(SRC)/jsg_internal.h include/jsg.h
+HIPFLAGS := -std=c++17 -O3 -fPIC -fvisibility=hidden -fvisibility-inlines-hidden -Iinclude --offload-arch=$(ARCH) -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=16
+KDEPS    := $(SRC)/jsg_stft_kernel.h $(SRC)/jsg_internal.h $(SRC)/jsg_exact_math.h include/jsg.h
 
 $(OBJ)/jsg_kernels.o: $(SRC)/jsg_kernels.hip $(KDEPS)
 	@mkdir -p $(OBJ)
@@ -25,9 +23,9 @@ $(OBJ)/jsg_stft_b.o: $(SRC)/jsg_stft_b.hip $(KDEPS)
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(OBJ)/%.o: $(SRC)/%.cpp $(SRC)/jsg_internal.h $(SRC)/jsg_colormap_tables.inc include/jsg.h
+$(OBJ)/%.o: $(SRC)/%.cpp $(SRC)/jsg_internal.h $(SRC)/jsg_block_queue.h $(SRC)/jsg_exact_math.h $(SRC)/jsg_colormap_tables.inc include/jsg.h
 	@mkdir -p $(OBJ)
-	$(HIPCC) -std=c++17 -O3 -fPIC -Iinclude -ffp-contract=off -D__HIP_PLATFORM_AMD__ -c $< -o $@
+	$(HIPCC) -std=c++17 -O3 -fPIC -fvisibility=hidden -fvisibility-inlines-hidden -Iinclude -ffp-contract=off -D__HIP_PLATFORM_AMD__ -c $< -o $@
 
 $(OUT): $(OBJ)/jsg_kernels.o $(OBJ)/jsg_stft_a.o $(OBJ)/jsg_stft_b.o $(OBJ)/jsg_engine.o $(OBJ)/jsg_host_math.o
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^

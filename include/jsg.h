@@ -29,6 +29,13 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* libjsg.so is built with -fvisibility=hidden: only the entry points declared here are exported. */
+#if defined(__GNUC__)
+#define JSG_API __attribute__((visibility("default")))
+#else
+#define JSG_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -71,26 +78,26 @@ typedef enum jsg_colorscheme {
     JSG_CM_PLASMA = 5, JSG_CM_JADE = 6
 } jsg_colorscheme;
 
-int jsg_abi_version(void);
+JSG_API int jsg_abi_version(void);
 /* Number of usable gfx950 devices (0 when there is none; never initialises a context). */
-int jsg_device_count(void);
+JSG_API int jsg_device_count(void);
 
 /* ------------------------------------------------------------------------------------------------
  * 1. Host-side precompute that feeds the kernels (pure integer / double arithmetic, no GPU).
  * ------------------------------------------------------------------------------------------------ */
 
 /* m_feed_samples = int(m_feed_percent*0.01*m_fftsize+0.5)           -- Spectrogram.cpp:216 */
-int jsg_feed_samples(float feed_percent, int fftsize);
+JSG_API int jsg_feed_samples(float feed_percent, int fftsize);
 /* m_memsize_blocks = int(m_memsize_s*m_fs/m_feed_samples + 0.5)     -- Spectrogram.cpp:217 */
-int jsg_memsize_blocks(float memsize_s, float fs, int feed_samples);
+JSG_API int jsg_memsize_blocks(float memsize_s, float fs, int feed_samples);
 /* Spectrogram::getnextpowerof2                                       -- Spectrogram.cpp:171-176 */
-int jsg_next_power_of_2(float fftsize_ms, float fs);
+JSG_API int jsg_next_power_of_2(float fftsize_ms, float fs);
 /* Spectrogram::setWindowFkt: n RMS-normalised window samples        -- Spectrogram.cpp:239-293 */
-int jsg_window_build(int window, int n, float* out);
+JSG_API int jsg_window_build(int window, int n, float* out);
 /* CColorPalette::ComputeColors: n_colors ints 0x00RRGGBB             -- CColorpalette.cpp:106-339 */
-int jsg_colormap_build(int n_colors, int scheme, int32_t* lut_out);
+JSG_API int jsg_colormap_build(int n_colors, int scheme, int32_t* lut_out);
 /* CColorPalette::setValueRange: resolves (lo,hi) -> m_Min, m_Max, m_AccessMult -- CColorpalette.cpp:39-54 */
-int jsg_colormap_range(int n_colors, float lo, float hi, float* vmin, float* vmax, float* access_mult);
+JSG_API int jsg_colormap_range(int n_colors, float lo, float hi, float* vmin, float* vmax, float* access_mult);
 
 /* ------------------------------------------------------------------------------------------------
  * 2. Stateless device operations.  Every data pointer is a DEVICE pointer on the current device;
@@ -101,9 +108,9 @@ int jsg_colormap_range(int n_colors, float lo, float hi, float* vmin, float* vma
  * `spectrum m_fft` member + m_window (Spectrogram.h:157-159; Spectrogram.cpp:215, :239-293).
  * `window` = n host floats; it is multiplied by sqrt(power_scale) when the tables are built. */
 typedef struct jsg_plan jsg_plan;
-int jsg_plan_create(jsg_plan** out, int n, const float* window, float power_scale);
-int jsg_plan_destroy(jsg_plan* plan);
-int jsg_plan_fft_size(const jsg_plan* plan);
+JSG_API int jsg_plan_create(jsg_plan** out, int n, const float* window, float power_scale);
+JSG_API int jsg_plan_destroy(jsg_plan* plan);
+JSG_API int jsg_plan_fft_size(const jsg_plan* plan);
 
 /* One launch of the fused kernel: framing + window + real FFT + |X|^2 + channel mix + 10*log10
  * + ring store.  Replaces the body of Spectrogram::processSynchronBlock's frame loop
@@ -153,19 +160,19 @@ typedef struct jsg_stft_args {
                                 place with a second, elementwise kernel (one more read + write of the output); the dB launches only
                                 (jsg_stft_db_launch, _strided, _batches, the engine via jsg_set_exact_log).  (was: reserved) */
 } jsg_stft_args;
-int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* args, void* stream);
+JSG_API int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* args, void* stream);
 /* The kernel configuration jsg_stft_db_launch picks for these arguments on the current device, as text ("Cfg1024", "Cfg2048",
  * "Cfg2048B", "Cfg4096B", ...; out_len >= 24): lets a benchmark or a test name -- and pin -- the kernel it times or checks. */
-int jsg_stft_kernel_name(const jsg_plan* plan, const jsg_stft_args* args, char* out, int out_len);
+JSG_API int jsg_stft_kernel_name(const jsg_plan* plan, const jsg_stft_args* args, char* out, int out_len);
 
 /* `count` independent launches issued from one call, launch i on streams[i % n_streams] (hipStream_t handles; NULL or
  * n_streams == 0: the default stream).  For batches that do not depend on each other (distinct input and output
  * buffers): takes the per-launch FFI cost out of the caller's loop and, with more than one stream, lets the tail of
  * one launch overlap the ramp-up of the next.  Ordering between the streams is the caller's business. */
-int jsg_stft_db_launch_many(const jsg_plan* plan, const jsg_stft_args* args, int count, void* const* streams, int n_streams);
+JSG_API int jsg_stft_db_launch_many(const jsg_plan* plan, const jsg_stft_args* args, int count, void* const* streams, int n_streams);
 /* The same issued by n_threads host threads (stream k belongs to thread k % n_threads, so the order inside a stream
  * is kept): for callers whose single issuing thread (~3.5 us per launch) is slower than the GPU. */
-int jsg_stft_db_launch_many_threads(const jsg_plan* plan, const jsg_stft_args* args, int count, void* const* streams,
+JSG_API int jsg_stft_db_launch_many_threads(const jsg_plan* plan, const jsg_stft_args* args, int count, void* const* streams,
                                     int n_streams, int n_threads);
 
 /* The overlapped mode as the LIBRARY's default: `count` independent launches (no two of them write the same ring columns),
@@ -185,7 +192,7 @@ int jsg_stft_db_launch_many_threads(const jsg_plan* plan, const jsg_stft_args* a
  * before it touches the GPU -- the plugin case; JSG_KEEP_HW_QUEUES=1 in the environment leaves it alone).  A host that keeps
  * other streams busy at the same time shares the four slots with them.  Calls for one device are serialised on the host.
  * Inside a stream capture (hipGraph) the launches are issued by the calling thread and become parallel branches of the graph. */
-int jsg_stft_db_launch_batches(const jsg_plan* plan, const jsg_stft_args* args, int count, void* stream);
+JSG_API int jsg_stft_db_launch_batches(const jsg_plan* plan, const jsg_stft_args* args, int count, void* stream);
 
 /* `n_batches` independent batches of ONE geometry in ONE kernel launch on ONE stream (the frame loop of
  * Spectrogram::processSynchronBlock, Spectrogram.cpp:50-119, over K streams' worth of blocks): `args` describes batch 0; batch b reads
@@ -199,21 +206,21 @@ int jsg_stft_db_launch_batches(const jsg_plan* plan, const jsg_stft_args* args, 
  *   with plan_select pinned to that plan.  All other sizes: bit-identical to single launches.
  * Max / Min mixes have no strided kernel: they are launched batch by batch in stream order.  More than 2^20 workgroup steps go out as
  * several launches.  jsg_stft_db_strided_kernel_name tells the kernel (as jsg_stft_kernel_name, for the total size). */
-int jsg_stft_db_launch_strided(const jsg_plan* plan, const jsg_stft_args* args, int n_batches, int64_t in_batch_stride,
+JSG_API int jsg_stft_db_launch_strided(const jsg_plan* plan, const jsg_stft_args* args, int n_batches, int64_t in_batch_stride,
                                int64_t out_batch_stride, void* stream);
-int jsg_stft_db_strided_kernel_name(const jsg_plan* plan, const jsg_stft_args* args, int n_batches, int64_t in_batch_stride, char* out,
+JSG_API int jsg_stft_db_strided_kernel_name(const jsg_plan* plan, const jsg_stft_args* args, int n_batches, int64_t in_batch_stride, char* out,
                                     int out_len);
 
 /* out[i] = 10*log10(power[i]/divisor + 1e-11f), i < count: the tail of the mix (reference Spectrogram.cpp:74,107)
  * for partial sums that were reduced across GPUs (JSG_MIX_SUM).  In place (out == power) is allowed. */
-int jsg_db_from_power_launch(const float* power, float* out, int64_t count, float divisor, void* stream);
+JSG_API int jsg_db_from_power_launch(const float* power, float* out, int64_t count, float divisor, void* stream);
 /* ... with the logarithm of jsg_stft_args.exact_log (1) instead of the hardware unit (0) */
-int jsg_db_from_power_launch_ex(const float* power, float* out, int64_t count, float divisor, int exact_log, void* stream);
+JSG_API int jsg_db_from_power_launch_ex(const float* power, float* out, int64_t count, float divisor, int exact_log, void* stream);
 
 /* Roofline calibration (no reference counterpart): a tuned float4 streaming copy of `bytes` bytes (multiple of 16, 16-byte aligned
  * device pointers), non-temporal loads and stores, one thread per 16 bytes.  bench.py times it on buffers that rotate over > 1 GB to
  * report what the HBM of THIS box gives a balanced read + write stream (`peak_copy_GBps`), the yardstick beside the 8 TB/s spec. */
-int jsg_calib_copy_launch(const void* src, void* dst, int64_t bytes, void* stream);
+JSG_API int jsg_calib_copy_launch(const void* src, void* dst, int64_t bytes, void* stream);
 
 /* Colour loop: dB ring columns -> ARGB pixels (and/or 8-bit palette indices).
  * Replaces the pixel loops of SpectrogramComponent::timerCallback (Spectrogram.cpp:632-648,
@@ -238,7 +245,7 @@ typedef struct jsg_colormap_args {
     uint8_t* index_out;      /* may be NULL; requires n_colors <= 256 */
     int64_t index_pitch;
 } jsg_colormap_args;
-int jsg_colormap_launch(const jsg_colormap_args* args, void* stream);
+JSG_API int jsg_colormap_launch(const jsg_colormap_args* args, void* stream);
 
 /* Fused display path: STFT -> palette index -> ARGB without the dB column ever going to memory (reference
  * Spectrogram.cpp:632-648: the colour loop consumes the column the engine has just produced).  The image is bit-identical to
@@ -258,8 +265,8 @@ typedef struct jsg_stft_image_args {
     uint8_t* index_scratch;        /* device: ring_width columns of index_scratch_pitch bytes each (two-kernel form only) */
     int64_t index_scratch_pitch;   /* >= n/2+1; a multiple of 64 keeps the columns line-aligned */
 } jsg_stft_image_args;
-int jsg_stft_image_launch(const jsg_plan* plan, const jsg_stft_image_args* args, void* stream);
-int jsg_stft_image_needs_scratch(const jsg_plan* plan, const jsg_stft_image_args* args);
+JSG_API int jsg_stft_image_launch(const jsg_plan* plan, const jsg_stft_image_args* args, void* stream);
+JSG_API int jsg_stft_image_needs_scratch(const jsg_plan* plan, const jsg_stft_image_args* args);
 /* `n_images` images of ONE geometry from one call (a batch of independent streams, or the pages of a long recording): `args`
  * describes one image; image i reads args->stft.in + i * in_image_stride (floats, >= 0) and writes args->colour.argb_out +
  * i * argb_image_stride (pixels, >= height * argb_pitch).  Where the single-kernel form applies to a launch of the TOTAL size
@@ -269,9 +276,9 @@ int jsg_stft_image_needs_scratch(const jsg_plan* plan, const jsg_stft_image_args
  * eight on 256 CUs: see DESIGN.md 4.4 for the measured gain).  Pixels: those of n_images jsg_stft_image_launch calls with plan_select pinned to the
  * plan the whole launch takes (the plan rule looks at the total column count).  Otherwise: n_images launches in stream order,
  * which need `index_scratch` like a single one (jsg_stft_image_strided_needs_scratch tells).  colour.index_out must be NULL. */
-int jsg_stft_image_launch_strided(const jsg_plan* plan, const jsg_stft_image_args* args, int n_images, int64_t in_image_stride,
+JSG_API int jsg_stft_image_launch_strided(const jsg_plan* plan, const jsg_stft_image_args* args, int n_images, int64_t in_image_stride,
                                   int64_t argb_image_stride, void* stream);
-int jsg_stft_image_strided_needs_scratch(const jsg_plan* plan, const jsg_stft_image_args* args, int n_images);
+JSG_API int jsg_stft_image_strided_needs_scratch(const jsg_plan* plan, const jsg_stft_image_args* args, int n_images);
 
 /* ------------------------------------------------------------------------------------------------
  * 3. Engine: the state of class Spectrogram (Spectrogram.h:81-169) living on the GPU.
@@ -280,46 +287,46 @@ typedef struct jsg_engine jsg_engine;
 
 /* Spectrogram::Spectrogram() defaults (Spectrogram.cpp:16-24): fs 48000, n 1024, feed 100 %, 1 s memory,
  * Hann, AbsMean.  `channels` is explicit (the plugin never calls setchannels). */
-int jsg_create(jsg_engine** out, int channels);
+JSG_API int jsg_create(jsg_engine** out, int channels);
 /* The same on an explicit HIP device (0 .. jsg_device_count()-1) instead of the calling thread's current one: what a
  * single-process host that drives several GPUs uses, one engine per device ("Several GPUs"). */
-int jsg_create_on_device(jsg_engine** out, int channels, int device);
-int jsg_get_device(const jsg_engine* e);
+JSG_API int jsg_create_on_device(jsg_engine** out, int channels, int device);
+JSG_API int jsg_get_device(const jsg_engine* e);
 /* One engine per entry of `devices` (entries may repeat), the `channels` channels of one stream dealt out in contiguous runs
  * whose sizes differ by at most one: entry i owns [first_channel[i], first_channel[i] + channel_count[i]) and gets no engine
  * (out[i] = NULL) when that run is empty.  The engines share nothing -- the path shards by independent channels, there is no
  * collective (a cross-GPU AbsMean is the one exchange: INTEGRATION.md C).  Configure every engine with the usual setters.
  * jsg_process_block_sharded hands every engine its run of the planar pointers (enqueue only); jsg_destroy_sharded frees the set. */
-int jsg_create_sharded(jsg_engine** out, int* first_channel, int* channel_count, const int* devices, int n_devices, int channels);
-int jsg_process_block_sharded(jsg_engine* const* engines, const int* first_channel, int n_devices, const float* const* planar);
-int jsg_destroy_sharded(jsg_engine** engines, int n_devices);
-int jsg_destroy(jsg_engine* e);
-const char* jsg_last_error(const jsg_engine* e);   /* e may be NULL: last error of the calling thread */
+JSG_API int jsg_create_sharded(jsg_engine** out, int* first_channel, int* channel_count, const int* devices, int n_devices, int channels);
+JSG_API int jsg_process_block_sharded(jsg_engine* const* engines, const int* first_channel, int n_devices, const float* const* planar);
+JSG_API int jsg_destroy_sharded(jsg_engine** engines, int n_devices);
+JSG_API int jsg_destroy(jsg_engine* e);
+JSG_API const char* jsg_last_error(const jsg_engine* e);   /* e may be NULL: last error of the calling thread */
 
 /* setters: each rebuilds the memory like Spectrogram::buildmem (Spectrogram.cpp:213-238) */
-int jsg_set_samplerate(jsg_engine* e, float fs);                 /* Spectrogram.cpp:148-152 */
-int jsg_set_channels(jsg_engine* e, int channels);               /* :153-157 */
-int jsg_set_fft_size(jsg_engine* e, int n);                      /* :160-170 */
-int jsg_set_closest_fft_size_ms(jsg_engine* e, float ms);        /* :177-183 */
-int jsg_set_memory_time_s(jsg_engine* e, float seconds);         /* :184-188 */
-int jsg_set_feed_percent(jsg_engine* e, int feed);               /* :189-211, jsg_feed */
-int jsg_set_feed_percent_ext(jsg_engine* e, float percent);      /* extension: any overlap, e.g. 12.5 */
-int jsg_set_pause_mode(jsg_engine* e, int paused);               /* Spectrogram.h:122 */
-int jsg_set_window(jsg_engine* e, int window);                   /* Spectrogram.h:123 */
-int jsg_set_window_table(jsg_engine* e, const float* w, int n);  /* extension: caller-supplied window */
-int jsg_set_mix_mode(jsg_engine* e, int mode);                   /* m_mode has no setter in the reference (:21) */
-int jsg_set_power_scale(jsg_engine* e, float scale);             /* normalisation of spectrum::power, default 1 */
-int jsg_set_exact_log(jsg_engine* e, int on);                    /* extension: jsg_stft_args.exact_log for the engine's launches (default 0);
+JSG_API int jsg_set_samplerate(jsg_engine* e, float fs);                 /* Spectrogram.cpp:148-152 */
+JSG_API int jsg_set_channels(jsg_engine* e, int channels);               /* :153-157 */
+JSG_API int jsg_set_fft_size(jsg_engine* e, int n);                      /* :160-170 */
+JSG_API int jsg_set_closest_fft_size_ms(jsg_engine* e, float ms);        /* :177-183 */
+JSG_API int jsg_set_memory_time_s(jsg_engine* e, float seconds);         /* :184-188 */
+JSG_API int jsg_set_feed_percent(jsg_engine* e, int feed);               /* :189-211, jsg_feed */
+JSG_API int jsg_set_feed_percent_ext(jsg_engine* e, float percent);      /* extension: any overlap, e.g. 12.5 */
+JSG_API int jsg_set_pause_mode(jsg_engine* e, int paused);               /* Spectrogram.h:122 */
+JSG_API int jsg_set_window(jsg_engine* e, int window);                   /* Spectrogram.h:123 */
+JSG_API int jsg_set_window_table(jsg_engine* e, const float* w, int n);  /* extension: caller-supplied window */
+JSG_API int jsg_set_mix_mode(jsg_engine* e, int mode);                   /* m_mode has no setter in the reference (:21) */
+JSG_API int jsg_set_power_scale(jsg_engine* e, float scale);             /* normalisation of spectrum::power, default 1 */
+JSG_API int jsg_set_exact_log(jsg_engine* e, int on);                    /* extension: jsg_stft_args.exact_log for the engine's launches (default 0);
                                                                     keeps the ring (no buildmem) */
 
-int jsg_get_spectrum_size(const jsg_engine* e);                  /* Spectrogram.h:127 */
-int jsg_get_memory_size(const jsg_engine* e);                    /* Spectrogram.h:128 */
-float jsg_get_samplerate(const jsg_engine* e);                   /* Spectrogram.h:130 */
-int jsg_get_fft_size(const jsg_engine* e);
-int jsg_get_feed_samples(const jsg_engine* e);
-int jsg_get_feedblocks(const jsg_engine* e);
-int jsg_get_channels(const jsg_engine* e);
-int jsg_get_window(const jsg_engine* e, float* out, int n);      /* copy of m_window */
+JSG_API int jsg_get_spectrum_size(const jsg_engine* e);                  /* Spectrogram.h:127 */
+JSG_API int jsg_get_memory_size(const jsg_engine* e);                    /* Spectrogram.h:128 */
+JSG_API float jsg_get_samplerate(const jsg_engine* e);                   /* Spectrogram.h:130 */
+JSG_API int jsg_get_fft_size(const jsg_engine* e);
+JSG_API int jsg_get_feed_samples(const jsg_engine* e);
+JSG_API int jsg_get_feedblocks(const jsg_engine* e);
+JSG_API int jsg_get_channels(const jsg_engine* e);
+JSG_API int jsg_get_window(const jsg_engine* e, float* out, int n);      /* copy of m_window */
 
 /* Spectrogram::processSynchronBlock (Spectrogram.cpp:37-135): `planar` = channels host pointers to fft-size samples each.
  * WAIT-FREE on the caller's (audio) thread: the block is copied into a page-locked single-producer ring and published with one
@@ -327,45 +334,45 @@ int jsg_get_window(const jsg_engine* e, float* out, int n);      /* copy of m_wi
  * a wait: when the ring is full (the GPU more than 64 blocks behind) or the engine is in the middle of a channel-count / FFT-size
  * change the block is DROPPED and counted.  Returns 0 (queued), 1 (dropped), < 0 (error -- also an error the worker thread met
  * earlier, text in jsg_last_error).  Readers, setters and jsg_sync see every block whose call returned before theirs began. */
-int jsg_process_block(jsg_engine* e, const float* const* planar);
+JSG_API int jsg_process_block(jsg_engine* e, const float* const* planar);
 /* The same for callers that state the geometry their pointers were sized for (host classes whose re-blocker runs unlocked beside
  * the FFT-size combo box): a block of another channel count or length than the engine's current one is dropped (returns 1)
  * instead of being read past its end.  0 = do not check that value. */
-int jsg_process_block_n(jsg_engine* e, const float* const* planar, int channels, int n);
+JSG_API int jsg_process_block_n(jsg_engine* e, const float* const* planar, int channels, int n);
 /* blocks dropped by jsg_process_block(_n) since the engine was created */
-long long jsg_get_dropped_blocks(const jsg_engine* e);
+JSG_API long long jsg_get_dropped_blocks(const jsg_engine* e);
 /* The same for n_blocks consecutive blocks in one launch: samples[c*pitch + i], i < n_blocks*n. */
-int jsg_process_blocks(jsg_engine* e, const float* samples, int64_t pitch, int n_blocks);
+JSG_API int jsg_process_blocks(jsg_engine* e, const float* samples, int64_t pitch, int n_blocks);
 /* The same with the samples already in HBM (device pointer, same layout); no host copy. */
-int jsg_process_blocks_device(jsg_engine* e, const float* d_samples, int64_t pitch, int n_blocks);
+JSG_API int jsg_process_blocks_device(jsg_engine* e, const float* d_samples, int64_t pitch, int n_blocks);
 
 /* Spectrogram::getMem (Spectrogram.cpp:295-331): dst is the caller's dense [dst_columns][n/2+1]
  * buffer; copies all columns when at least a ring-full is new, else only the new ones (in place,
  * wrap-aware); returns the new-column count and zeroes it, -1 on size mismatch. */
-int jsg_get_mem(jsg_engine* e, float* dst, int dst_columns, int* pos);
+JSG_API int jsg_get_mem(jsg_engine* e, float* dst, int dst_columns, int* pos);
 /* The same into the reference's own container shape, vector<vector<float>> mem[W][H] (Spectrogram.h:144): rows[c]
  * points to the row_len = n/2+1 floats of column c (a NULL row is skipped); only the new columns are touched. */
-int jsg_get_mem_rows(jsg_engine* e, float* const* rows, int n_rows, int row_len, int* pos);
+JSG_API int jsg_get_mem_rows(jsg_engine* e, float* const* rows, int n_rows, int row_len, int* pos);
 /* Extension: all columns of the ring as they are now, without consuming the new-column counter (returns the counter). */
-int jsg_peek_mem(jsg_engine* e, float* dst, int dst_columns, int* pos);
+JSG_API int jsg_peek_mem(jsg_engine* e, float* dst, int dst_columns, int* pos);
 /* Device pointer / geometry of the dB ring (stays valid until the next setter). */
-int jsg_ring_device(jsg_engine* e, float** d_ring, int64_t* pitch, int* width, int* pos);
-int jsg_sync(jsg_engine* e);
-void* jsg_stream(jsg_engine* e);                                  /* the engine's hipStream_t */
+JSG_API int jsg_ring_device(jsg_engine* e, float** d_ring, int64_t* pitch, int* width, int* pos);
+JSG_API int jsg_sync(jsg_engine* e);
+JSG_API void* jsg_stream(jsg_engine* e);                                  /* the engine's hipStream_t */
 
 /* ------------------------------------------------------------------------------------------------
  * 4. Display: the colour half of SpectrogramComponent::timerCallback (Spectrogram.cpp:590-731).
  * ------------------------------------------------------------------------------------------------ */
 /* CColorPalette(n_colors, scheme) / setColorSceme (Spectrogram.cpp:337, :400); forces a full recolour */
-int jsg_display_set_colormap(jsg_engine* e, int n_colors, int scheme);
+JSG_API int jsg_display_set_colormap(jsg_engine* e, int n_colors, int scheme);
 /* m_isRunningDisplay (Spectrogram.cpp:745-759) */
-int jsg_display_set_running(jsg_engine* e, int running);
+JSG_API int jsg_display_set_running(jsg_engine* e, int running);
 /* m_recomputeAll = true (colour sliders, Spectrogram.cpp:370,379) */
-int jsg_display_invalidate(jsg_engine* e);
+JSG_API int jsg_display_invalidate(jsg_engine* e);
 /* One timer tick: consumes the new columns (like getMem), colours them (all of them when a recolour is
  * pending) and writes the [height][width] ARGB image into host memory `argb` (`pitch` pixels per row).
  * min_color/max_color are the slider values (Spectrogram.cpp:614-617). */
-int jsg_display_update(jsg_engine* e, float min_color, float max_color, uint32_t* argb, int64_t pitch,
+JSG_API int jsg_display_update(jsg_engine* e, float min_color, float max_color, uint32_t* argb, int64_t pitch,
                        int* new_vals, int* pos);
 
 /* Incremental tick for hosts that scroll their own image like the reference (moveImageSection + fill of the
@@ -373,13 +380,13 @@ int jsg_display_update(jsg_engine* e, float min_color, float max_color, uint32_t
  * ([height][tile_pitch] pixels, oldest column first).  Returns 0 and *new_vals (<= max_cols) columns; returns 1
  * (nothing consumed) when a full recolour is pending or more than max_cols columns are new -- then call
  * jsg_display_update for the whole image. */
-int jsg_display_update_tile(jsg_engine* e, float min_color, float max_color, uint32_t* tile, int64_t tile_pitch,
+JSG_API int jsg_display_update_tile(jsg_engine* e, float min_color, float max_color, uint32_t* tile, int64_t tile_pitch,
                             int max_cols, int* new_vals, int* pos);
 
 /* The frequency window of SpectrogramComponent::paint (Spectrogram.cpp:441-459): which image rows show
  * [min_freq, max_freq] Hz.  Pure host arithmetic (same clamps and roundings); outputs displayStartPixel,
  * displayEndPixel, heightInterval and hStart (= height - displayEndPixel, the first image row to blit). */
-int jsg_display_freq_rows(float fs, int height, float min_freq, float max_freq, int* start_pixel, int* end_pixel,
+JSG_API int jsg_display_freq_rows(float fs, int height, float min_freq, float max_freq, int* start_pixel, int* end_pixel,
                           int* height_interval, int* h_start);
 
 #ifdef __cplusplus

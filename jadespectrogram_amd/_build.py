@@ -18,6 +18,8 @@ HEADERS = ["jsg_internal.h", "jsg_block_queue.h", "jsg_exact_math.h", "jsg_stft_
 #       SLP pass pairs unrelated scalars and pays ~140 register moves per FFT
 #   -amdgpu-kernarg-preload-count: the leading scalar kernel arguments are delivered in SGPRs
 HIP_FLAGS = ["-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
+# every unit: only the C-ABI of include/jsg.h (JSG_API) leaves the library; the launchers, plan helpers and module probes stay inside
+VISIBILITY = ["-fvisibility=hidden", "-fvisibility-inlines-hidden"]
 # ... and per unit: the ILP-first machine scheduler for the 512 / 1024 / 2048 / 8192-point kernels (jsg_stft_a.hip explains and
 # gives the measurements); the 4096-point kernels (jsg_stft_b.hip) keep the default one
 UNIT_FLAGS = {"jsg_stft_a.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
@@ -39,9 +41,9 @@ def _stale(target: str, deps) -> bool:
 
 
 def build_variant(name: str, hip_flags, verbose: bool = False) -> str:
-    """DEV: an experimental build of the library with extra device-compile flags (-D switches of jsg_kernels.hip,
-    -mllvm options ...) as tools/variants/libjsg_<name>.so, for tools/abbench (A/B of several builds in one process).
-    The product build below never uses these."""
+    """DEV: an experimental build of the library with extra device-compile flags (-mllvm options, -D switches of a patched tree ...) as
+    tools/variants/libjsg_<name>.so, for tools/abbench and tools/strided_probe.py (A/B of several builds).  The product build below
+    never uses these."""
     hipcc = _hipcc()
     vdir = os.path.join(ROOT, "tools", "variants")
     objdir = os.path.join(PKG, "build", "variants", name)
@@ -58,7 +60,7 @@ def build_variant(name: str, hip_flags, verbose: bool = False) -> str:
             continue
         objs.append(o)
         cmd = [hipcc, "-std=c++17", "-O3", "-fPIC", "-c", s, "-o", o, "-I", os.path.join(ROOT, "include"),
-               f"--offload-arch={ARCH}"] + HIP_FLAGS + ([] if os.environ.get("JSG_NO_UNIT_FLAGS") else UNIT_FLAGS.get(src, [])) + list(hip_flags)
+               f"--offload-arch={ARCH}"] + VISIBILITY + HIP_FLAGS + ([] if os.environ.get("JSG_NO_UNIT_FLAGS") else UNIT_FLAGS.get(src, [])) + list(hip_flags)
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
@@ -72,11 +74,8 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
-    # JSG_DEV_VARIANTS=1: also compile the development variants of the kernels (tools/sweep_variants.sh, stamps.py ...);
-    # the product build holds the default plans only
-    dev = os.environ.get("JSG_DEV_VARIANTS", "") not in ("", "0")
     flavour_file = os.path.join(objdir, "flavour")
-    flavour = "dev" if dev else "product"
+    flavour = "product"
     if not os.path.exists(flavour_file) or open(flavour_file).read().strip() != flavour:
         force = True
     objs = []
@@ -87,11 +86,9 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
             recompiled.append(src)
-            cmd = [hipcc, "-std=c++17", "-O3", "-fPIC", "-c", s, "-o", o, "-I", os.path.join(ROOT, "include")]
+            cmd = [hipcc, "-std=c++17", "-O3", "-fPIC", "-c", s, "-o", o, "-I", os.path.join(ROOT, "include")] + VISIBILITY
             if src.endswith(".hip"):
                 cmd += [f"--offload-arch={ARCH}"] + HIP_FLAGS + UNIT_FLAGS.get(src, [])
-                if dev:
-                    cmd.append("-DJSG_DEV_VARIANTS")
             else:
                 # host translation units: keep float arithmetic exactly as written (bit parity with the reference)
                 cmd += ["-ffp-contract=off", "-D__HIP_PLATFORM_AMD__"]

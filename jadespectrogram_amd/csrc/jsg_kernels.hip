@@ -174,73 +174,16 @@ struct jsg_plan {
     float2* d_tab_b = nullptr;   // 2048 / 4096 points: lane tables of the second plan (Cfg2048B / Cfg4096B), behind d_tab in the same allocation
 };
 
-static unsigned long long* g_dev_stamps = nullptr;   // development builds: stamp buffer of the ABL == 3 variants
-
-#ifdef JSG_DEV_VARIANTS
-// development only: tuned streaming copy, the physical floor for "move these bytes once" at a given launch size
-template <bool NT>
-__global__ __launch_bounds__(256) void dev_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const v4f* s = reinterpret_cast<const v4f*>(src);
-    v4f* d = reinterpret_cast<v4f*>(dst);
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        const v4f a = s[i], b = s[i + stride], c = s[i + 2 * stride], e = s[i + 3 * stride];
-        if (NT) {
-            __builtin_nontemporal_store(a, &d[i]); __builtin_nontemporal_store(b, &d[i + stride]);
-            __builtin_nontemporal_store(c, &d[i + 2 * stride]); __builtin_nontemporal_store(e, &d[i + 3 * stride]);
-        } else { d[i] = a; d[i + stride] = b; d[i + 2 * stride] = c; d[i + 3 * stride] = e; }
-    }
-    for (; i < n4; i += stride) {
-        if (NT) __builtin_nontemporal_store(s[i], &d[i]); else d[i] = s[i];
-    }
-}
-
-#endif   // JSG_DEV_VARIANTS
 extern "C" {
 
-#ifdef JSG_DEV_VARIANTS
-// development only: the same copy with the STFT kernel's access widths (8-byte loads, 4-byte nt stores)
-__global__ __launch_bounds__(256) void dev_copy_narrow_kernel(const float2* __restrict__ src, float* __restrict__ dst, long long n2) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n2; i += 4 * stride) {
-        const float2 a = src[i], b = src[i + stride], c = src[i + 2 * stride], e = src[i + 3 * stride];
-        float* d0 = dst + 2 * (i - (i % blockDim.x));   // keep each store instruction 256 B contiguous per wave
-        const long long l = i % blockDim.x;
-        __builtin_nontemporal_store(a.x, &d0[l]); __builtin_nontemporal_store(a.y, &d0[l + blockDim.x]);
-        float* d1 = d0 + 2 * stride; __builtin_nontemporal_store(b.x, &d1[l]); __builtin_nontemporal_store(b.y, &d1[l + blockDim.x]);
-        float* d2 = d1 + 2 * stride; __builtin_nontemporal_store(c.x, &d2[l]); __builtin_nontemporal_store(c.y, &d2[l + blockDim.x]);
-        float* d3 = d2 + 2 * stride; __builtin_nontemporal_store(e.x, &d3[l]); __builtin_nontemporal_store(e.y, &d3[l + blockDim.x]);
-    }
-}
-
-// development only (not part of include/jsg.h): streaming copy microbenchmark (tools/copy_floor.py)
-int jsg_dev_copy_launch(const void* src, void* dst, long long bytes, int blocks, int nt, void* stream) {
-    const long long n4 = bytes / 16;
-    if (nt == 2) {
-        hipLaunchKernelGGL(dev_copy_narrow_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                           static_cast<const float2*>(src), static_cast<float*>(dst), bytes / 8);
-        return hipGetLastError() == hipSuccess ? 0 : -4;
-    }
-    if (nt) hipLaunchKernelGGL(dev_copy_kernel<true>, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                               static_cast<const float4*>(src), static_cast<float4*>(dst), n4);
-    else hipLaunchKernelGGL(dev_copy_kernel<false>, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                            static_cast<const float4*>(src), static_cast<float4*>(dst), n4);
-    return hipGetLastError() == hipSuccess ? 0 : -4;
-}
-
-// development only (not part of include/jsg.h): device buffer for the s_memtime stamps of variant 'S'
-void jsg_dev_set_stamp_buffer(void* p) { g_dev_stamps = static_cast<unsigned long long*>(p); }
-
-#endif   // JSG_DEV_VARIANTS (none of the jsg_dev_* entry points exists in the product library)
 
 int jsg_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
+
+static void pool_prepare_for_device(int dev);
 
 int jsg_plan_create(jsg_plan** out, int n, const float* window, float power_scale) {
     if (!out || !window) return jsg_fail(JSG_ERR_INVALID, "jsg_plan_create: null argument");
@@ -306,6 +249,7 @@ int jsg_plan_create(jsg_plan** out, int n, const float* window, float power_scal
         return jsg_fail_hip(err, "jsg_plan_create");
     }
     if (tab_b_at) p->d_tab_b = p->d_tab + tab_b_at;
+    pool_prepare_for_device(p->device);
     *out = p;
     return JSG_OK;
 }
@@ -418,7 +362,6 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     ka.ring_w = g->ring_width;
     ka.ring_pos = g->ring_pos;
     ka.tab = plan->d_tab;
-    ka.stamps = g_dev_stamps;
     if (io) {
         ka.argb = io->argb;
         ka.argb_pitch = io->argb_pitch;
@@ -624,6 +567,8 @@ int jsg_stft_image_launch(const jsg_plan* plan, const jsg_stft_image_args* g, vo
     if (c.n_cols != g->stft.n_frames || c.ring_width != g->stft.ring_width || c.height != plan->n / 2 + 1 ||
         (c.col_first % c.ring_width) != g->stft.ring_pos)
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch: the colour loop must cover exactly the columns of the launch");
+    if (c.argb_out && (c.x_wrap <= 0 || c.argb_pitch < c.x_wrap))   // (a zero, negative or too small pitch would be out-of-bounds device writes)
+        return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch: argb_pitch must be at least x_wrap pixels");
     // Single kernel where the plan's workgroups hold eight whole columns (1024 points; 4096 points: the one-wavefront-per-frame
     // kernel): the workgroup colours its columns itself and writes ARGB rows -- nothing but the input is read, nothing but the
     // image is written.  Everything else: index columns through `index_scratch` + the colour kernel.
@@ -658,6 +603,14 @@ int jsg_stft_image_launch_strided(const jsg_plan* plan, const jsg_stft_image_arg
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch_strided: bad colour geometry");
     if (in_image_stride < 0 || (c.argb_out && argb_image_stride < (long long)c.height * c.argb_pitch))
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch_strided: the images would overlap (argb_image_stride < height * argb_pitch) or a stride is negative");
+    if (c.argb_out && c.argb_pitch < c.x_wrap)
+        return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch_strided: argb_pitch must be at least x_wrap pixels");
+    // in_samples describes the rows of EVERY image: with a stride the rows of one image must end before the next image begins (a stride
+    // of 0 = the same input for every image)
+    if (g->stft.in_samples != 0 && in_image_stride != 0 &&
+        in_image_stride < (long long)(g->stft.channels - 1) * g->stft.in_pitch + g->stft.in_samples)
+        return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch_strided: in_image_stride is smaller than one image's input rows "
+                                         "((channels - 1) * in_pitch + in_samples); 0 = the same input for all images");
     if (c.n_cols != g->stft.n_frames || c.ring_width != g->stft.ring_width || c.height != plan->n / 2 + 1 ||
         (c.col_first % c.ring_width) != g->stft.ring_pos)
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch_strided: the colour loop must cover exactly the columns of the launch");
@@ -808,7 +761,40 @@ struct LaunchPool {
 LaunchPool g_pools[64];
 constexpr int kPoolStreams = 4;    // working streams (the caller's + 3): 3 streams 1.25e9, 4 streams 1.32e9, 5 and more 0.5-0.8e9 frames/s at C2 (round 2)
 constexpr int kPoolThreads = 2;    // one host thread issues a launch every ~3.5 us, the GPU finishes one every ~3.1-3.9 us
+
+// streams and events of a device's pool, all or nothing (p.mu held)
+int pool_ensure(LaunchPool& p) {
+    if (p.ready) return JSG_OK;
+    hipError_t err = hipSuccess;
+    for (int i = 0; i < 3 && err == hipSuccess; ++i) {
+        err = hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming);
+    }
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&p.fork, hipEventDisableTiming);
+    if (err != hipSuccess) {   // give back what was created: the next call starts from nothing again
+        for (int i = 0; i < 3; ++i) {
+            if (p.join[i]) (void)hipEventDestroy(p.join[i]);
+            if (p.s[i]) (void)hipStreamDestroy(p.s[i]);
+            p.join[i] = nullptr;
+            p.s[i] = nullptr;
+        }
+        if (p.fork) (void)hipEventDestroy(p.fork);
+        p.fork = nullptr;
+        return jsg_fail_hip(err, "jsg_stft_db_launch_batches: creating the launch pool");
+    }
+    p.ready = true;
+    return JSG_OK;
+}
 }  // namespace
+
+// called by jsg_plan_create: the pool of the plan's device exists before any launch, so the first jsg_stft_db_launch_batches may
+// already sit inside a stream capture
+static void pool_prepare_for_device(int dev) {
+    if (dev < 0 || dev >= 64) return;
+    LaunchPool& p = g_pools[dev];
+    std::lock_guard<std::mutex> lk(p.mu);
+    (void)pool_ensure(p);
+}
 
 int jsg_stft_db_launch_batches(const jsg_plan* plan, const jsg_stft_args* args, int count, void* stream) {
     if (!plan || (!args && count > 0) || count < 0) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch_batches: bad argument");
@@ -820,17 +806,16 @@ int jsg_stft_db_launch_batches(const jsg_plan* plan, const jsg_stft_args* args, 
     LaunchPool& p = g_pools[dev];
     std::lock_guard<std::mutex> lk(p.mu);
     hipError_t err = hipSuccess;
-    if (!p.ready) {
-        for (int i = 0; i < 3 && err == hipSuccess; ++i) {
-            err = hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking);
-            if (err == hipSuccess) err = hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming);
-        }
-        if (err == hipSuccess) err = hipEventCreateWithFlags(&p.fork, hipEventDisableTiming);
-        if (err != hipSuccess) return jsg_fail_hip(err, "jsg_stft_db_launch_batches: creating the launch pool");
-        p.ready = true;
-    }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(user, &cap);
+    if (!p.ready) {
+        // (jsg_plan_create has normally done this already: pool_ensure; a stream cannot be created in the middle of a capture)
+        if (cap == hipStreamCaptureStatusActive)
+            return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch_batches: the launch pool of this device does not exist yet and cannot be created "
+                                             "inside a stream capture (create the plan on this device first, or call once outside the capture)");
+        const int rc = pool_ensure(p);
+        if (rc != JSG_OK) return rc;
+    }
     // launches of the one-workgroup-per-CU kernels (2048 / 4096 "B") fill the GPU by themselves: two streams are enough to hide
     // the ramp-up and drain (measured at C3, round 2), four make them queue behind each other
     int nc0 = args[0].channels;
@@ -839,18 +824,27 @@ int jsg_stft_db_launch_batches(const jsg_plan* plan, const jsg_stft_args* args, 
     const int n_s = count < want_s ? count : want_s;     // working streams: sv[0] = the caller's, sv[1..] = the library's
     // fork: the library's streams start behind everything already enqueued on the caller's stream
     err = hipEventRecord(p.fork, user);
-    for (int i = 0; i + 1 < n_s && err == hipSuccess; ++i) err = hipStreamWaitEvent(p.s[i], p.fork, 0);
-    if (err != hipSuccess) return jsg_fail_hip(err, "jsg_stft_db_launch_batches: fork");
+    int forked = 0;      // library streams that wait for the fork event: every one of them is joined below, whatever happens in between
+    for (int i = 0; i + 1 < n_s && err == hipSuccess; ++i) {
+        err = hipStreamWaitEvent(p.s[i], p.fork, 0);
+        if (err == hipSuccess) ++forked;
+    }
     void* sv[kPoolStreams] = {user, p.s[0], p.s[1], p.s[2]};
     // (the default stream cannot be named by a null handle in a round-robin table: launch_many treats NULL as "default stream" too)
-    const int rc = jsg_stft_db_launch_many_threads(plan, args, count, sv, n_s, cap == hipStreamCaptureStatusActive ? 1 : kPoolThreads);
-    // join (also after a failed launch: what was enqueued must still be ordered before the caller's later work)
-    for (int i = 0; i + 1 < n_s && err == hipSuccess; ++i) {
-        err = hipEventRecord(p.join[i], p.s[i]);
-        if (err == hipSuccess) err = hipStreamWaitEvent(user, p.join[i], 0);
+    int rc = JSG_OK;
+    if (err == hipSuccess)
+        rc = jsg_stft_db_launch_many_threads(plan, args, count, sv, n_s, cap == hipStreamCaptureStatusActive ? 1 : kPoolThreads);
+    // join (also after a failed fork or launch: what was enqueued must still be ordered before the caller's later work, and a capture
+    // must not be left with branches that never come back)
+    hipError_t jerr = hipSuccess;
+    for (int i = 0; i < forked; ++i) {
+        hipError_t e1 = hipEventRecord(p.join[i], p.s[i]);
+        if (e1 == hipSuccess) e1 = hipStreamWaitEvent(user, p.join[i], 0);
+        if (e1 != hipSuccess && jerr == hipSuccess) jerr = e1;
     }
+    if (err != hipSuccess) return jsg_fail_hip(err, "jsg_stft_db_launch_batches: fork");
     if (rc != JSG_OK) return rc;
-    if (err != hipSuccess) return jsg_fail_hip(err, "jsg_stft_db_launch_batches: join");
+    if (jerr != hipSuccess) return jsg_fail_hip(jerr, "jsg_stft_db_launch_batches: join");
     return JSG_OK;
 }
 
@@ -894,6 +888,8 @@ static int colormap_launch_impl(const jsg_colormap_args* g, const unsigned char*
         return jsg_fail(JSG_ERR_INVALID, "jsg_colormap_launch: more columns than the ring holds");
     if (g->index_out && g->n_colors > 256)
         return jsg_fail(JSG_ERR_INVALID, "jsg_colormap_launch: the 8-bit index plane needs n_colors <= 256");
+    if ((g->argb_out && g->argb_pitch < g->x_wrap) || (g->index_out && g->index_pitch < g->x_wrap))
+        return jsg_fail(JSG_ERR_INVALID, "jsg_colormap_launch: image pitch smaller than x_wrap (rows would overlap / leave the image)");
     if (g->n_colors > 65535) return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_colormap_launch: n_colors > 65535");
     CmapKArgs ka{};
     ka.db = g->db;

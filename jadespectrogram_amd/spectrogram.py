@@ -450,6 +450,8 @@ def stft_image_strided(plan: Plan, d_in, hop: int, n_frames: int, d_lut, lo: flo
     (stft_image_strided_needs_scratch() tells), else k launches in stream order."""
     import torch
     assert d_in.dim() == 3 and d_argb.dim() == 3 and d_in.shape[0] == d_argb.shape[0] and d_in.stride(2) == 1 and d_argb.stride(2) == 1
+    assert d_argb.shape[1] >= plan.n // 2 + 1, "image rows: one per bin"
+    assert d_in.shape[0] == 1 or d_in.stride(0) == 0 or d_in.stride(0) >= (d_in.shape[1] - 1) * d_in.stride(1) + d_in.shape[2], "images overlap in the input"
     a = _stft_image_args(plan, d_in[0], hop, n_frames, d_lut, lo, hi, d_argb[0], d_index_scratch, **kw)
     if stream is None:
         stream = torch.cuda.current_stream(d_in.device).cuda_stream
