@@ -441,12 +441,14 @@ def test_grid_shape_ring_position_and_ring_alignment_do_not_change_the_bits(jsg,
     _spot_check(oracle, d_in, ref[frames][:, :H].cpu().numpy(), n, hop, win, frames)
 
 
-@pytest.mark.parametrize("cfg,kernel,max_share_beyond_1e5", [("c2", "Cfg1024", 0.01), ("c3", "Cfg2048B", 1e-4), ("c5", "Cfg4096B", 0.002)])
+@pytest.mark.parametrize("cfg,kernel,max_share_beyond_1e5", [("c2", "Cfg1024", 0.01), ("c3", "Cfg2048B", 2e-5), ("c5", "Cfg4096B", 0.002)])
 def test_baseline_config_accuracy_contract(jsg, oracle, torch_cuda, cfg, kernel, max_share_beyond_1e5):
     """The accuracy contract of DESIGN.md section 2 as regression guards, on the BASELINE configurations at their full launch
     size and with the kernel the benchmark times (bench.parity_report is the code that fills the bench line's "parity" block):
-      * share of bins whose relative power error against the float64 DFT exceeds plain 1e-5: C2 <= 1 %, C3 <= 0.01 % (3 of 524 800 bins with the "B" kernel), C5 <= 0.2 %
-        (all of them far below their frame's peak), and plain 5e-6 on every bin within 20 dB of the peak;
+      * share of bins whose relative power error against the float64 DFT exceeds plain 1e-5: C2 <= 1 % (measured 0.78 %), C3 <= 0.002 %
+        (measured: 3 of 524 800 bins = 0.0006 % with the "B" kernel -- a count, so the guard is 10 bins, three standard deviations of a
+        Poisson count of 3, not the 52 bins the 1e-4 of round 3 allowed), C5 <= 0.2 % (measured 0.11 %) -- all of them at least 30 dB below
+        their frame's peak -- and plain 5e-6 on every bin within 20 dB of the peak;
       * error relative to the frame peak <= FLOOR(n) (tests/parity_util.py);
       * colour indices end to end (GPU power -> dB -> index against oracle power -> dB -> index): at most 1 per 50 000 pixels;
       * the fused image equals the two-kernel image.
