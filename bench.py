@@ -167,11 +167,11 @@ def cpu_baseline(c, seconds_budget: float = 10.0):
     return res
 
 
-# Vector instructions per FFT of the kernels the configurations time (SQ_INSTS_VALU / FFTs, profiles/r03_*_hbm_traffic.json ->
+# Vector instructions per FFT of the kernels the configurations time (SQ_INSTS_VALU / FFTs, profiles/r04_*_hbm_traffic.json ->
 # derived) and the shader clock the chip holds under that load (C3: SQ_WAVE_CYCLES x 4 / waves = 67.7 k cycles per wave over a
 # 40.4 us dispatch = 1.68 GHz -- well under the 2.4 GHz maximum: packed-math kernels are power-limited): the issue roof of the
 # compute-bound configurations (a wave64 VALU instruction holds its SIMD for 4 cycles; 256 CUs x 4 SIMDs).
-VALU_PER_FFT = {"c2": 221.0, "c3": 372.0, "c5": 1112.0}
+VALU_PER_FFT = {"c2": 180.0, "c3": 366.0, "c5": 1099.0}
 CLOCK_GHZ_UNDER_LOAD = 1.7
 
 
