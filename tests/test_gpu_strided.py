@@ -168,3 +168,42 @@ def test_strided_bad_arguments_are_rejected(jsg, oracle, torch_cuda):
     assert lib.jsg_stft_db_launch_strided(plan._p, C.byref(a), 3, ok_in, 0, st) == jsg.capi.JSG_ERR_INVALID
     assert lib.jsg_stft_db_launch_strided(None, C.byref(a), 3, ok_in, ok_out, st) == jsg.capi.JSG_ERR_INVALID
     torch.cuda.synchronize()
+
+
+def _fuzz_cases(default):
+    import os
+    return int(os.environ.get("JSG_FUZZ_CASES", default))
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("JSG_FUZZ_STRIDED_SEEDS", "4"))))
+def test_seeded_random_strided_db_batches(jsg, oracle, torch_cuda, seed):
+    """Random plan / channel count / mix / hop pattern / frame count / batch count / ring geometry / grid size: the strided dispatch
+    against single launches, bit for bit (JSG_FUZZ_CASES widens the sweep)."""
+    import os
+    rng = np.random.default_rng(1000 + seed + 97 * int(os.environ.get("JSG_FUZZ_SEED", "0")))
+    cap = jsg.capi
+    cases = max(12, _fuzz_cases(48) // 4)
+    for _ in range(cases):
+        n = int(rng.choice([512, 1024, 1024, 2048, 4096, 8192]))
+        C = int(rng.choice([1, 1, 2, 3, 8]))
+        mix = [cap.MIX_ABSMEAN, cap.MIX_ABSMEAN, cap.MIX_SUM, cap.MIX_LEFT, cap.MIX_PER_CHANNEL, cap.MIX_MAX][int(rng.integers(0, 6))]
+        if mix == cap.MIX_MAX and C == 1:
+            mix = cap.MIX_ABSMEAN
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            hop, fb = n // 2, 2
+        elif kind == 1:
+            hop, fb = n // 4, 4
+        elif kind == 2:
+            hop, fb = int(0.1 * n + 0.5), 10            # the reference's perc10: irregular last hop
+        else:
+            hop, fb = int(rng.integers(1, n // 8)) * 4, 1   # a free hop (feedblocks 1: regular only when hop == n)
+            fb = 1
+        budget = 3.0e6 / n                              # keep a case small: frames x batches x channels
+        F = int(rng.integers(1, max(2, int(min(1500, budget / C)))))
+        K = int(rng.integers(2, max(3, int(min(40, budget * 4 / (F * C))))))
+        W = F + int(rng.integers(0, 50))
+        pos = int(rng.integers(0, W))
+        bpc = int(rng.choice([0, 0, 1, 3, 7]))
+        _run_case(jsg, oracle, torch_cuda, n, C, F, K, hop, fb=fb, mix=mix, W=W, ring_pos=pos, first_frame=int(rng.integers(0, 5)), blocks_per_cu=bpc,
+                  linear=bool(rng.integers(0, 4) == 0))
