@@ -6,6 +6,9 @@
 // thread alternates jsg_get_mem (up to 15 MB device-to-host) and jsg_display_update (colour kernel + 15 MB image copy)
 // without pause.  Afterwards the ring must be bit-identical to a second engine that was fed the same samples in one
 // batch, undisturbed.  Prints one JSON line; the pytest wrapper asserts the bounds.
+#include <pthread.h>
+#include <sched.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -70,6 +73,23 @@ int main(int argc, char** argv) {
         }
     });
 
+    // An audio thread has a core (and usually a real-time priority) of its own; an ordinary user cannot ask for the priority, but it can
+    // keep the measurement's own busy threads off the producer's core: the producer takes the last CPU this process may use, the
+    // consumer (and whatever else the process starts) the others.
+    {
+        cpu_set_t all;
+        CPU_ZERO(&all);
+        if (sched_getaffinity(0, sizeof all, &all) == 0 && CPU_COUNT(&all) >= 4) {
+            int last = -1;
+            for (int c = 0; c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &all)) last = c;
+            cpu_set_t mine, rest = all;
+            CPU_ZERO(&mine);
+            CPU_SET(last, &mine);
+            CPU_CLR(last, &rest);
+            (void)pthread_setaffinity_np(consumer.native_handle(), sizeof rest, &rest);
+            (void)pthread_setaffinity_np(pthread_self(), sizeof mine, &mine);
+        }
+    }
     std::vector<double> lat;
     lat.reserve(size_t(blocks));
     for (int b = 0; b < blocks; ++b) {
