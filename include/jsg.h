@@ -175,23 +175,22 @@ JSG_API int jsg_stft_db_launch_many(const jsg_plan* plan, const jsg_stft_args* a
 JSG_API int jsg_stft_db_launch_many_threads(const jsg_plan* plan, const jsg_stft_args* args, int count, void* const* streams,
                                     int n_streams, int n_threads);
 
-/* The overlapped mode as the LIBRARY's default: `count` independent launches (no two of them write the same ring columns),
- * stream-ordered with respect to `stream` like one launch -- they start after everything that was enqueued on `stream` before
- * the call, and work enqueued on `stream` after the call sees all their results -- but spread over FOUR working streams: the
- * caller's own plus three that the library owns (created once per device), issued by two host threads, so that the ramp-up
- * and drain of consecutive launches overlap (C2: ~3.8 us per 4096-frame launch instead of ~5.4 us in order; bench.py).  Two
- * working streams for the one-workgroup-per-CU kernels of 2048 / 4096 points.  The caller neither creates streams nor knows the
- * good stream count; it must not enqueue on `stream` from another thread during the call.
- * Hardware queues: the GPU's compute front end serves four hardware queues at a time.  A FIFTH busy queue makes the command
- * processor time-slice them (measured at C2: 1.08e9 frames/s with four busy queues, 0.35e9 with five) -- which is why the
- * caller's stream is one of the four working streams and not a fifth beside them -- and two busy streams that the HIP runtime
- * maps onto ONE hardware queue serialise (0.98e9).  The runtime multiplexes all streams of the process onto GPU_MAX_HW_QUEUES
- * queues (default 4); when the variable is not set, loading libjsg.so sets GPU_MAX_HW_QUEUES=16 for the process so that the
- * working streams get queues of their own beside whatever streams the host has created (measured with nine streams in the
- * process: 0.79 / 0.41 / 0.84 / 1.08 / 1.08e9 frames/s at 4 / 6 / 8 / 12 / 16 queues) (it is read at the first HIP call, i.e. this works for a host that loads the library
- * before it touches the GPU -- the plugin case; JSG_KEEP_HW_QUEUES=1 in the environment leaves it alone).  A host that keeps
- * other streams busy at the same time shares the four slots with them.  Calls for one device are serialised on the host.
- * Inside a stream capture (hipGraph) the launches are issued by the calling thread and become parallel branches of the graph. */
+/* Independent launches that CANNOT be laid out at a stride (otherwise: jsg_stft_db_launch_strided below, one kernel launch for all of
+ * them): `count` launches (no two of them write the same ring columns), stream-ordered with respect to `stream` like one launch -- they
+ * start after everything that was enqueued on `stream` before the call, and work enqueued on `stream` after the call sees all their
+ * results -- but spread over FOUR working streams: the caller's own plus three that the library owns (created once per device, in
+ * jsg_plan_create), issued by two host threads, so that the ramp-up and drain of consecutive launches overlap.  Two working streams for
+ * the one-workgroup-per-CU kernels of 2048 / 4096 points.  The caller neither creates streams nor knows the good stream count; it must
+ * not enqueue on `stream` from another thread during the call.
+ * Hardware queues: the GPU's compute front end serves four hardware queues at a time.  A FIFTH busy queue makes the command processor
+ * time-slice them (measured at C2: 1.08e9 frames/s with four busy queues, 0.35e9 with five) -- which is why the caller's stream is one of
+ * the four working streams and not a fifth beside them -- and two busy streams that the HIP runtime maps onto ONE hardware queue
+ * serialise.  The runtime multiplexes all streams of the process onto GPU_MAX_HW_QUEUES queues (default 4) in creation order (measured
+ * with nine streams in the process: 0.79 / 0.41 / 0.84 / 1.08 / 1.08e9 frames/s at 4 / 6 / 8 / 12 / 16 queues): a host that wants this
+ * entry point at its full rate exports GPU_MAX_HW_QUEUES=16 itself before its first HIP call.  The library does not touch the
+ * environment (rounds 2-3 set the variable from a constructor: not thread-safe inside a multi-threaded host, and it changed every
+ * other HIP user of the process).  Calls for one device are serialised on the host.  Inside a stream capture (hipGraph) the launches are
+ * issued by the calling thread and become parallel branches of the graph; every forked stream is joined even when a launch fails. */
 JSG_API int jsg_stft_db_launch_batches(const jsg_plan* plan, const jsg_stft_args* args, int count, void* stream);
 
 /* `n_batches` independent batches of ONE geometry in ONE kernel launch on ONE stream (the frame loop of
