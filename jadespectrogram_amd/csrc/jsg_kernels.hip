@@ -665,7 +665,9 @@ int jsg_stft_db_launch_strided(const jsg_plan* plan, const jsg_stft_args* g, int
     if (g->n_frames < 0 || g->channels <= 0) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch_strided: bad geometry");
     const long long rows_per_batch = g->mix_mode == JSG_MIX_PER_CHANNEL ? g->channels : 1;
     // at most 2^20 workgroup steps per launch (the kernel's group -> row arithmetic): longer jobs go out in several launches
-    const long long steps_per_batch = rows_per_batch * ((g->n_frames + 7) / 8);
+    // (counted with the smallest workgroup step of the plan's kernels: 16 / 8 / 4 / 2 / 1 columns at 512 ... 8192 points)
+    const int tpb_min = plan->n == 512 ? Cfg512::TPB : plan->n == 1024 ? Cfg1024::TPB : plan->n == 2048 ? Cfg2048::TPB : plan->n == 4096 ? Cfg4096::TPB : Cfg8192::TPB;
+    const long long steps_per_batch = rows_per_batch * ((g->n_frames + tpb_min - 1) / tpb_min);
     const long long per_launch = one_by_one ? 1 : std::max(1ll, (1ll << 20) / std::max(1ll, steps_per_batch));
     for (long long b0 = 0; b0 < n_batches; b0 += per_launch) {
         const int nb = int(std::min<long long>(per_launch, n_batches - b0));
