@@ -244,6 +244,34 @@ def test_offline_render_example_runs(jsg):
         assert info["one_kernel_for_the_batch"] is True
 
 
+def _build_offline_db_example(jsg):
+    libdir = os.path.dirname(jsg.capi.LIB_PATH)
+    exe = os.path.join(tempfile.gettempdir(), "jsg_offline_db_batches_example")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+                           "-isystem", "/opt/rocm/include", os.path.join(ROOT, "tests", "cpp", "offline_db_batches_example.cpp"), "-o", exe,
+                           "-L", libdir, "-ljsg", f"-Wl,-rpath,{libdir}", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"])
+    return exe
+
+
+def test_offline_db_batches_example_compiles_and_links(jsg):
+    """The C++ worked example of jsg_stft_db_launch_strided (many independent dB batches of one geometry)."""
+    assert os.path.exists(_build_offline_db_example(jsg))
+
+
+@pytest.mark.gpu
+def test_offline_db_batches_example_runs(jsg):
+    """32 mono streams of 4096 frames through ONE strided launch from a C++ host equal 32 single launches column for column, with the
+    hardware logarithm and with exact_log; the padding behind the columns stays untouched."""
+    exe = _build_offline_db_example(jsg)
+    r = subprocess.run([exe, "32", "4096"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    print(info)
+    if "skipped" not in info:
+        assert info["columns_differing"] == 0 and info["columns_differing_exact_log"] == 0 and info["padding_floats_touched"] == 0
+        assert info["kernel"] == "Cfg1024" and info["us_per_batch_one_strided_launch"] < info["us_per_batch_one_launch_each"]
+
+
 def _build_rccl_example(jsg):
     libdir = os.path.dirname(jsg.capi.LIB_PATH)
     exe = os.path.join(tempfile.gettempdir(), "jsg_rccl_absmean_example")
