@@ -193,6 +193,20 @@ def test_producer_is_wait_free_under_a_reading_consumer(jsg):
 
 
 @pytest.mark.gpu
+def test_engine_geometry_storm_under_a_pushing_audio_thread(jsg):
+    """The epoch protocol with the real engine: a message thread changes FFT size / channel count 60 times and reads the ring in
+    between while the audio thread pushes blocks sized for the geometry it was last told about.  No error, no crash; blocks of a
+    stale geometry are dropped and counted (return code == counter); afterwards the engine equals a fresh one bit for bit."""
+    exe = _build_against_lib(jsg, "engine_geometry_race_test.cpp", "jsg_engine_geometry_race")
+    r = subprocess.run([exe, "60"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    print(info)
+    assert info["errors"] == 0 and info["differing_floats_after_the_storm"] == 0 and info["queued"] > 0
+    assert info["dropped_by_return_code"] == info["dropped_blocks_counter"]
+
+
+@pytest.mark.gpu
 def test_full_ring_drops_and_counts_instead_of_blocking(jsg):
     """Pushed without any pause the audio thread outruns the GPU: the ring (64 blocks) fills up, further blocks are dropped -- return
     value 1, jsg_get_dropped_blocks -- and no call takes longer than before."""
