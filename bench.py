@@ -27,6 +27,8 @@ measured live with HIP events on that stream around the K steps: achieved = algo
 `timed_region_frac` (bytes of the K steps / wall) is the same number up to the host's last synchronize.  rocprofv3's per-dispatch
 average of the same command is committed under profiles/ (tools/profile_bench.sh) and quoted beside it when it was recorded with
 the same kernel sources.  `calibration` = what a tuned float4 copy (jsg_calib_copy_launch) reaches on this box: the measured roof.
+`power` = the same steps kept running for --power-seconds (after the timed region, N = 1) with the card's socket power and core clock
+sampled from its hwmon files: every kernel of this path runs the socket into its 1400 W cap, the core clock gives.
 
 Every rank works on its own batches (weak scaling; the path shards by channel / stream, there is no data-path collective); RCCL
 carries only the barriers and the max-over-ranks time.  At N = 1 the default line also carries the c3 and c5 results (`extra`), from
@@ -175,13 +177,18 @@ VALU_PER_FFT = {"c2": 180.0, "c3": 366.0, "c5": 1099.0}
 CLOCK_GHZ_UNDER_LOAD = 1.7
 
 
-def valu_roof(c, units_per_launch, inorder_us):
+def valu_roof(c, units_per_launch, inorder_us, sclk_mhz=None):
+    """Vector-issue roof: every SIMD issuing one vector instruction every 4 cycles, at the core clock the card SUSTAINS under this
+    workload (measured by the `power` leg when the telemetry is readable: the socket sits at its power cap and the clock gives,
+    DESIGN.md section 6) -- else at the ~1.7 GHz of earlier rounds' estimate."""
     key = {1024: "c2", 2048: "c3", 4096: "c5"}[c["n"]]
+    ghz = sclk_mhz / 1e3 if sclk_mhz else CLOCK_GHZ_UNDER_LOAD
     ffts = units_per_launch * (c["channels"] if c["colour"] else 1)
-    roof = 1024 * CLOCK_GHZ_UNDER_LOAD * 1e9 / (4.0 * VALU_PER_FFT[key])          # FFT/s with every SIMD issuing every cycle
+    roof = 1024 * ghz * 1e9 / (4.0 * VALU_PER_FFT[key])          # FFT/s with every SIMD issuing every cycle
     got = ffts / (inorder_us * 1e-6)
-    return {"bound": "valu_issue", "achieved": got, "peak": roof, "unit": "FFT/s", "frac": got / roof,
-            "note": f"{VALU_PER_FFT[key]:.0f} vector instructions per FFT (PMC) x 4 cycles on 1024 SIMDs at ~{CLOCK_GHZ_UNDER_LOAD} GHz under load; "
+    return {"bound": "valu_issue", "achieved": got, "peak": roof, "unit": "FFT/s", "frac": got / roof, "clock_GHz": ghz,
+            "clock_source": "hwmon, median over the sustained leg of this run" if sclk_mhz else "estimate",
+            "note": f"{VALU_PER_FFT[key]:.0f} vector instructions per FFT (PMC) x 4 cycles on 1024 SIMDs at the core clock under this load; "
                     "C3 and C5 are bound here, not by HBM (DESIGN.md section 6)"}
 
 
@@ -302,6 +309,53 @@ def parity_report(jsg, c, plan, d_in_host, win):
             "note": "float64 DFT of the float32 windowed frames is the yardstick; indices: Jade, 256 colours, -50..50 dB"}
 
 
+def power_report(torch, lib, stream, run_step, units_per_step, bytes_per_step, seconds, dev_index):
+    """What the card draws while the path runs: the same steps for `seconds`, and the calibration copy for a shorter while, with the
+    socket power and the core clock sampled from the card's hwmon files (tools/hwmon.py; read-only).  The STFT kernels run the socket
+    INTO ITS POWER CAP (1400 W) with the core clock pulled down to 1.7-1.9 GHz, while a pure copy at 0.82 of 8 TB/s stays near 1100 W at
+    the full 2.4 GHz: DESIGN.md section 6, 'power'.  Returns None when the telemetry files are not there."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from hwmon import Hwmon, Watch
+    except ImportError:
+        return None
+    hw = Hwmon(dev_index)
+    if not hw.ok:
+        return None
+
+    def leg(fn, per_call_units, per_call_bytes, secs):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        calls, t0 = 0, time.perf_counter()
+        with Watch(hw, settle_s=min(1.0, secs / 3)) as w:
+            e0.record(stream)
+            while time.perf_counter() - t0 < secs:
+                for _ in range(4):
+                    fn()
+                calls += 4
+                if calls % 16 == 0:
+                    stream.synchronize()
+            e1.record(stream)
+            torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        r = {"seconds": round(ms / 1e3, 2), "GBps": per_call_bytes * calls / ms / 1e6, "frac_of_8TBps": per_call_bytes * calls / ms / 1e6 / HBM_PEAK_GBS}
+        if per_call_units:
+            r["units_per_s"] = per_call_units * calls / ms * 1e3
+        r.update(w.summary())
+        return r
+
+    half = 1 << 30
+    pool = torch.empty(2 * half // 4, dtype=torch.float32, device="cuda").uniform_(-1, 1)
+    src, dst, h = ctypes.c_void_p(pool.data_ptr()), ctypes.c_void_p(pool.data_ptr() + half), ctypes.c_void_p(stream.cuda_stream)
+    out = {"cap_W": hw.cap_W(),
+           "path_sustained": leg(run_step, units_per_step, bytes_per_step, seconds),
+           "copy_sustained": leg(lambda: lib.jsg_calib_copy_launch(src, dst, half, h), 0, 2 * half, max(1.5, seconds / 2)),
+           "source": os.path.join(hw.dir, hw.power_file),
+           "note": "the same steps as the timed region, kept running; socket power and core clock are medians of 0.1 s samples after a settling "
+                   "time.  At the cap the core clock is what gives: the path is power-bound there (DESIGN.md section 6)"}
+    del pool
+    return out
+
+
 def calibrate_copy(lib, torch, stream):
     """The roof on THIS box: jsg_calib_copy_launch (float4, non-temporal loads and stores, non-looping grid) on buffers that rotate over
     2 x 1 GiB -- 1 GiB per launch, and the byte counts of one 65 536-frame launch (134 MB each way) and of one C2 batch (8.4 MB each way).
@@ -340,7 +394,7 @@ def run_extra_config(cfg):
     """c3 / c5 as a child process (started before this process touches the GPU): their headline numbers for the driver's line."""
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-boundary",
-                            "--no-extra", "--no-calibration", "--sub-run"], capture_output=True, text=True, timeout=400)
+                            "--no-extra", "--no-calibration", "--power-seconds", "2", "--sub-run"], capture_output=True, text=True, timeout=400)
         j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         return {"metric": j["metric"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "step": j["config"]["step"],
                 "workload": j["config"]["workload"], "kernel": j["roofline"]["kernel"],
@@ -348,7 +402,8 @@ def run_extra_config(cfg):
                                                            "timed_region_frac", "frac_rocprof", "traffic", "second_roof") if k in j["roofline"]},
                 "parity": {k: j["parity"][k] for k in ("kernel", "frac_bins_rel_power_err_gt_1e-5", "max_err_relative_to_frame_peak", "colour_index_flips_end_to_end",
                                                        "pixels_checked", "strided_pixels_differing_from_single_launches", "strided_columns_differing_from_single_launches")
-                           if k in j.get("parity", {})}}
+                           if k in j.get("parity", {})},
+                "power": ({"cap_W": j["power"].get("cap_W"), "path_sustained": j["power"].get("path_sustained")} if j.get("power") else None)}
     except Exception as e:   # a reported figure, never a reason to lose the bench line
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
@@ -369,6 +424,8 @@ def main():
     ap.add_argument("--no-boundary", action="store_true", help="skip the `boundary` block (jsg_process_block latency, PCIe-inclusive rate)")
     ap.add_argument("--no-extra", action="store_true", help="skip the c3 / c5 child runs of the default line")
     ap.add_argument("--no-calibration", action="store_true", help="skip the copy-roof calibration")
+    ap.add_argument("--no-power", action="store_true", help="skip the sustained leg that samples socket power and core clock")
+    ap.add_argument("--power-seconds", type=float, default=3.0, help="length of the sustained leg (N=1 only; after the timed region)")
     ap.add_argument("--no-single", action="store_true", help="skip the one-batch-per-dispatch leg")
     ap.add_argument("--sub-run", action="store_true", help="(internal) this process is a child of another bench.py")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work at all: exercises the N-rank plumbing (barriers, reductions, "
@@ -539,6 +596,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dispatch_us = float(t[0]), (float(t[1]) or None)
 
+    power = None
+    if rank == 0 and not args.dry_run and world == 1 and not args.no_power:
+        power = power_report(torch, lib, one, run_step, units_per_batch * bpd * dps, algo_batch * bpd * dps, args.power_seconds, dev_index)
     if rank == 0 and not args.dry_run and world == 1 and not args.no_calibration:
         calibration = calibrate_copy(lib, torch, one)
     if rank == 0 and not args.dry_run and world == 1 and not args.no_parity:
@@ -617,7 +677,7 @@ def main():
             "frac_rocprof": (algo / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rocprof_us else None,
             "frac_of_measured_copy_roof": (achieved / calibration["peak_copy_GBps"]) if calibration else None,
             "traffic": traffic, "traffic_source": tsrc, "kernel": kernel_label,
-            "second_roof": valu_roof(c, units_per_batch * bpd, dispatch_us),
+            "second_roof": valu_roof(c, units_per_batch * bpd, dispatch_us, ((power or {}).get("path_sustained") or {}).get("sclk_MHz_median")),
             "commit": commit,
         }
         if single_us:
@@ -625,6 +685,8 @@ def main():
                 "what": f"the same batches, ONE jsg_stft_db_launch per {F}-frame batch, in order on one stream (hipGraph replay of the rotation, HIP events)",
                 "avg_dispatch_us": single_us, "algorithmic_bytes_per_dispatch": algo_batch, "frac": algo_batch / (single_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "units_per_s": units_per_batch / (single_us * 1e-6)}
+    if power is not None:
+        out["power"] = power
     if calibration is not None:
         out["calibration"] = calibration
     if parity is not None:

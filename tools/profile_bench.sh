@@ -13,9 +13,9 @@ cd /tmp && export TMPDIR=/tmp
 # The timed region of bench.py IS a sequence of back-to-back dispatches of one kernel on one stream, host-issued by plain C calls: the
 # tracer sees exactly what the bench times.  The side legs (parity, calibration, one-batch-per-dispatch, child runs) are switched off so
 # that the trace holds the main kernel only; otherwise this is the driver's command.
-CMD="python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --steps 20 --warmup 5 --no-cpu-baseline --no-boundary --no-parity --no-extra --no-calibration --no-single"
+CMD="python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --steps 20 --warmup 5 --no-cpu-baseline --no-boundary --no-parity --no-extra --no-calibration --no-single --no-power"
 # counter passes: the same dispatches, fewer of them (the collector serialises every dispatch); counters are per-dispatch means
-PMC_CMD="python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --steps 3 --warmup 1 --dispatches-per-step 2 --no-cpu-baseline --no-boundary --no-parity --no-extra --no-calibration --no-single"
+PMC_CMD="python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --steps 3 --warmup 1 --dispatches-per-step 2 --no-cpu-baseline --no-boundary --no-parity --no-extra --no-calibration --no-single --no-power"
 echo "$CMD" > $OUT/command.txt
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1 || echo "stats pass failed"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $PMC_CMD > $OUT/fetch.log 2>&1 || echo "fetch pass failed"
