@@ -236,7 +236,7 @@ int jsg_plan_create(jsg_plan** out, int n, const float* window, float power_scal
     hipError_t err = hipSuccess;
     switch (n) {
         case 512: err = ensure_attrs_Cfg512(); break;
-        case 1024: err = ensure_attrs_Cfg1024(); break;
+        case 1024: err = ensure_attrs_Cfg1024(); if (err == hipSuccess) err = ensure_attrs_Cfg1024I(); break;
         case 2048: err = ensure_attrs_Cfg2048(); if (err == hipSuccess) err = ensure_attrs_Cfg2048B(); break;
         case 4096: err = ensure_attrs_Cfg4096(); if (err == hipSuccess) err = ensure_attrs_Cfg4096B(); break;
         case 8192: err = ensure_attrs_Cfg8192(); break;
@@ -429,7 +429,7 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     int tpb = 0;
     switch (plan->n) {
         case 512: tpb = Cfg512::TPB; break;
-        case 1024: tpb = Cfg1024::TPB; break;
+        case 1024: tpb = (io && io->argb) ? Cfg1024I::TPB : Cfg1024::TPB; break;   // (the display path's eight-column workgroups)
         case 2048: tpb = plan_b ? Cfg2048B::TPB : Cfg2048::TPB; break;
         case 4096: tpb = plan_b ? Cfg4096B::TPB : Cfg4096::TPB; break;
         case 8192: tpb = Cfg8192::TPB; break;
@@ -493,7 +493,7 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     }
     switch (plan->n) {
         case 512: err = launch_Cfg512(ka, mixop, grid, s); break;
-        case 1024: err = launch_Cfg1024(ka, mixop, grid, s); break;
+        case 1024: err = (io && io->argb) ? launch_Cfg1024I(ka, mixop, grid, s) : launch_Cfg1024(ka, mixop, grid, s); break;
         case 2048: err = plan_b ? launch_Cfg2048B(ka, mixop, grid, s) : launch_Cfg2048(ka, mixop, grid, s); break;
         case 4096: err = plan_b ? launch_Cfg4096B(ka, mixop, grid, s) : launch_Cfg4096(ka, mixop, grid, s); break;
         case 8192: err = launch_Cfg8192(ka, mixop, grid, s); break;

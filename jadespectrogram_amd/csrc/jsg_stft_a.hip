@@ -9,6 +9,7 @@
 namespace jsg {
 JSG_DEFINE_PLAN(Cfg512)
 JSG_DEFINE_PLAN(Cfg1024)
+JSG_DEFINE_PLAN(Cfg1024I)
 JSG_DEFINE_PLAN(Cfg2048)
 JSG_DEFINE_PLAN(Cfg2048B)
 JSG_DEFINE_PLAN(Cfg8192)

@@ -283,9 +283,17 @@ struct Cfg {
 };
 
 using Cfg512 = Cfg<512, 8, 8, 4, 32, 36, 4, 33, 1, 8, 1, 2>;   // (a 80-VGPR budget = 3 workgroups per CU measured no faster)
-// six waves per SIMD = three 8-wave workgroups per CU (their LDS allows exactly three): <= 80 VGPRs for EVERY instantiation.  Left at 2
-// the ILP-first scheduler takes 88 for the mixing instantiations (two workgroups per CU): stereo -2..-4 % with the cap
-using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 6>;
+// <= 80 VGPRs for EVERY instantiation (six waves per SIMD allowed).  Left at 2 the ILP-first scheduler takes 88 for the mixing
+// instantiations: stereo -2..-4 % with the cap.
+// Workgroups of FOUR waves (four frames per step; five workgroups = 20 waves per CU, 29.5 KB of LDS each) since the end of round 4, where
+// rounds 1-4 had eight (three workgroups = 24 waves per CU): measured with tools/pool_probe.py / strided_probe.py on six boxes, variant
+// builds of the same source -- the C2 dispatch +2.3..+2.7 % on five boxes (0.582-0.585 -> 0.594-0.601 of 8 TB/s) and -1.9 % on one
+// (0.648 -> 0.636), the C4 shard (8 channels, one column each) +5.9 %, 75 % overlap +11 %, single launches of <= 1024 frames +14 %, two
+// channels mixed level, eight channels mixed -3.5 %.  Workgroups of 2 waves: +1 %; of 3, 5, 6 waves: -4..-5 %.
+using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 4, 1, 6>;
+// ... and the eight-wave form for the single-kernel display path (OUTK == 2), whose store phase is laid out for eight columns per step;
+// same tables, same arithmetic per frame (bit-identical columns); instantiated for that path only (image_only)
+using Cfg1024I = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 6>;
 // factorised stage-2 / post tables (Cfg::TWF): 11.3 instead of 21.2 KB of tables, so that THREE 4-wave workgroups fit a CU (12 waves
 // instead of 8): stereo launches -9..-13 %, mono -1..-5 %
 using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 1, 3, 1, 0, 1>;   // (6-, 8-, 12-wave workgroups: no faster)
@@ -1136,9 +1144,17 @@ hipError_t ensure_lds_attr() {
 // plans that can colour their own columns (stft_db_kernel, OUTK == 2): one wavefront per frame, eight frames per workgroup
 template <class C>
 constexpr bool image_ok = C::L == 64 && C::FPW == 1 && C::TPB == 8 && C::WPB == 8 && C::LDS_TOTAL + 1024 <= 160 * 1024;
+// configurations that exist for the single-kernel display path alone (nothing else is instantiated for them)
+template <class C>
+constexpr bool image_only = std::is_same<C, Cfg1024I>::value;
 
 template <class C>
 hipError_t ensure_lds_attrs_of_plan() {
+    if constexpr (image_only<C>) {
+        hipError_t e = ensure_lds_attr<C, 0, 2>();
+        if (e == hipSuccess) e = ensure_lds_attr<C, 3, 2>();
+        return e;
+    } else {
     hipError_t e = ensure_lds_attr<C, 0, 0>();
     if (e == hipSuccess) e = ensure_lds_attr<C, 1, 0>();
     if (e == hipSuccess) e = ensure_lds_attr<C, 2, 0>();
@@ -1152,6 +1168,7 @@ hipError_t ensure_lds_attrs_of_plan() {
         if (e == hipSuccess) e = ensure_lds_attr<C, 3, 2>();
     }
     return e;
+    }
 }
 
 template <class C, int MIXOP, int OUTK = 0, int STREAM = 0>
@@ -1174,6 +1191,8 @@ hipError_t launch_stft(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s)
         }
         return hipErrorInvalidValue;
     }
+    if constexpr (image_only<C>) return hipErrorInvalidValue;
+    else {
     if (ka.idx) {   // fused display path: the mixed (AbsMean / Sum) and the one-channel instantiations only
         if (mixop == 3) return launch_stft_mix<C, 3, 1>(ka, grid, s);
         if (mixop == 0) return launch_stft_mix<C, 0, 1>(ka, grid, s);
@@ -1185,15 +1204,19 @@ hipError_t launch_stft(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s)
         case 3: return launch_stft_mix<C, 3>(ka, grid, s);
         default: return launch_stft_mix<C, 0>(ka, grid, s);
     }
+    }
 }
 
 // strided multi-batch launches (STREAM == 1): the sum-mixed and the one-channel instantiations
 template <class C, int STREAM>
 hipError_t launch_stft_strided(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s) {
-    if (ka.argb || ka.idx) return hipErrorInvalidValue;
-    if (mixop == 3) return launch_stft_mix<C, 3, 0, STREAM>(ka, grid, s);
-    if (mixop == 0) return launch_stft_mix<C, 0, 0, STREAM>(ka, grid, s);
-    return hipErrorInvalidValue;
+    if constexpr (image_only<C>) return hipErrorInvalidValue;
+    else {
+        if (ka.argb || ka.idx) return hipErrorInvalidValue;
+        if (mixop == 3) return launch_stft_mix<C, 3, 0, STREAM>(ka, grid, s);
+        if (mixop == 0) return launch_stft_mix<C, 0, 0, STREAM>(ka, grid, s);
+        return hipErrorInvalidValue;
+    }
 }
 
 
@@ -1202,7 +1225,7 @@ hipError_t launch_stft_strided(const StftKArgs& ka, int mixop, dim3 grid, hipStr
 // jsg_stft_b.hip: JSG_STFT_PLANS below); jsg_kernels.hip reaches them through these plain functions only, so no kernel is
 // ever compiled twice and hipFuncSetAttribute always addresses the one copy that is launched.
 // ------------------------------------------------------------------------------------------------------------
-#define JSG_FOR_EACH_PLAN(X) X(Cfg512) X(Cfg1024) X(Cfg2048) X(Cfg2048B) X(Cfg4096) X(Cfg4096B) X(Cfg8192)
+#define JSG_FOR_EACH_PLAN(X) X(Cfg512) X(Cfg1024) X(Cfg1024I) X(Cfg2048) X(Cfg2048B) X(Cfg4096) X(Cfg4096B) X(Cfg8192)
 #define JSG_DECLARE_PLAN(C)                                                                   \
     hipError_t launch_##C(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s);          \
     hipError_t launch_strided_##C(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s);  \

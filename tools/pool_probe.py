@@ -12,6 +12,8 @@ import ctypes, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import jadespectrogram_amd as jsg
+if os.environ.get("PP_LIB"):          # a variant build (python -m jadespectrogram_amd._build --variant NAME ...)
+    jsg.capi.LIB_PATH = os.path.abspath(os.environ["PP_LIB"])
 
 n, hop, F, K = 1024, 512, 4096, 64
 H, pitch = 513, int(os.environ.get("PP_PITCH", 544))
@@ -68,5 +70,5 @@ for r in range(rounds):
     for p, pool in enumerate(held):
         stft[p].append(round(t_stft(pool), 4))
         copy[p].append(round(t_copy(pool), 4))
-print(json.dumps({"pid": os.getpid(), "pools": pools, "pool_gib": gib, "stft_frac_per_pool": stft, "copy_frac_per_pool": copy,
+print(json.dumps({"lib": os.environ.get("PP_LIB", "product"), "pid": os.getpid(), "pools": pools, "pool_gib": gib, "stft_frac_per_pool": stft, "copy_frac_per_pool": copy,
                   "addr_gib": [round(h.data_ptr() / (1 << 30), 2) for h in held]}))
