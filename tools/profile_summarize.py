@@ -84,7 +84,7 @@ for kname, d in res["counters_mean_per_dispatch"].items():
                                                                               ("waiting_to_issue_lds", "SQ_WAIT_INST_LDS")) if v in d},
            "lds_bank_conflict_share_of_lds_cycles": (d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]) if d.get("SQ_LDS_IDX_ACTIVE") else None,
            "lds_array_cycles_per_fft": d.get("SQ_LDS_IDX_ACTIVE", 0.0) / ffts,
-           "note": "issuing_valu x (waves per SIMD: 6 at C2, 2 at C3 / C5) = share of the time a SIMD's vector pipe is issuing"}
+           "note": "issuing_valu x (waves per SIMD: 5 at C2, 2 at C3 / C5) = share of the time a SIMD's vector pipe is issuing"}
     res.setdefault("derived", {})[kname] = der
 json.dump(res, open(os.path.join(dst, f"{tag}_{cfg}_hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
