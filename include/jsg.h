@@ -198,7 +198,7 @@ JSG_API int jsg_stft_db_launch_batches(const jsg_plan* plan, const jsg_stft_args
  * args->in + b * in_batch_stride (floats; 0 = the same input) and writes its own ring at args->out_db + b * out_batch_stride (floats,
  * at least one ring: the rings must not overlap).  Everything else in `args` (frame count, hop, ring_pos, mix, in_samples -- which then
  * holds for the rows of EVERY batch) is the same for all batches.  The workgroups of the one launch walk through the columns of all
- * batches: lane tables loaded once per workgroup instead of once per eight frames, no ramp-up and drain per batch, the next columns in
+ * batches: lane tables loaded once per workgroup instead of once per step of four to sixteen frames, no ramp-up and drain per batch, the next columns in
  * flight while the current ones are transformed -- the rate of back-to-back launches without extra streams, hardware queues or issuing
  * threads (bench.py's default C2 step).  args->blocks_per_cu: workgroups per CU of the grid (0 = the library's choice).
  *   2048 / 4096 points: the plan rule of plan_select looks at the frames of the WHOLE launch; columns are those of single launches
