@@ -500,11 +500,24 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     cf* const lds0 = reinterpret_cast<cf*>(smem_raw) + (slot0 + sub * F) * C::LDS_ELEMS;   // frame f: lds0 + f * LDS_ELEMS
     const int tl = ll;                                            // index into a lane-table row (TL = L entries)
 
-    // XCD-aware block remap (bijective): blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD one
-    // contiguous range of frames so that the overlapped halves of neighbouring frames hit the same L2.
+    // XCD-aware block remap (bijective): blocks b, b+8, b+16.. share an XCD (and its L2); neighbouring workgroups are given to the
+    // same XCD so that the overlapped halves of neighbouring frames hit the same L2 -- in CHUNKS of 32 workgroups that alternate between
+    // the XCDs (logical blocks [256 s + 32 x, +32) belong to XCD x), so that the eight XCDs together still sweep one contiguous window
+    // of the stream.  (Rounds 2-4 gave every XCD one contiguous EIGHTH of the grid, i.e. eight sweeps 1/8 of the launch apart: the C2
+    // dispatch 0.599 -> 0.606-0.610 of 8 TB/s with chunks of 1..64, 0.602 with 128; a grid of 256 -- the "B" plans -- is the same either
+    // way.)  The blocks behind the last whole 256 (all of them in a grid below 256, e.g. the 253 workgroups of a C5 dispatch) share
+    // one contiguous range per XCD among themselves, as every grid did before: left to their own numbers, neighbouring workgroups land on
+    // different XCDs and the 32-byte pieces of an image row line no longer meet in one L2 (C5: traffic 1.10 -> 1.31 x, 584 -> 646 us).
     const unsigned nblk = k_nblk, b = blockIdx.x;   // == gridDim.x (a hidden kernel argument: would cost an s_load)
-    const unsigned q = nblk >> 3, r = nblk & 7, xcd = b & 7;
-    const unsigned lb = a.xcd_remap ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3) : b;
+    const unsigned xcd = b & 7, jb = b >> 3, full = nblk & ~255u;
+    unsigned lb = b;
+    if (a.xcd_remap) {
+        if (b < full) lb = ((jb >> 5) << 8) + (xcd << 5) + (jb & 31u);
+        else {
+            const unsigned t = nblk - full, q = t >> 3, r = t & 7;   // (full is a multiple of 8: block b - full sits on XCD b & 7 too)
+            lb = full + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ((b - full) >> 3);
+        }
+    }
 
     // ---- task bookkeeping (32-bit, scalar): task t of this launch is frame t; the channel range is fixed ----
     // Grid-stride traversal: in iteration `it` the workgroups cover one contiguous window of gridDim.x*TPB frames that
