@@ -8,6 +8,8 @@
 //   MAP 0  static grid-stride, workgroup b takes steps b, b + grid, ...                       (neighbours on different XCDs)
 //   MAP 1  ... with every XCD given one contiguous eighth of the grid                          (the kernel's remap of rounds 2-4)
 //   MAP 2  ... with chunks of 32 workgroups alternating between the XCDs                       (the kernel's remap now)
+//   (map 4 in the output: MAP 2 with 16-byte loads -- 1 KB per wave-instruction, four per frame -- which the FFT's lane layout does not allow:
+//          what the 8-byte loads cost)
 //   MAP 3  dynamic: eight ticket counters, one per XCD; a workgroup draws its next step one step ahead; ticket t of XCD x is step
 //          256 (t / 32) + 32 x + t % 32 -- the chip-wide front then advances as ONE contiguous window no matter how the workgroups drift
 #include <hip/hip_runtime.h>
@@ -26,8 +28,9 @@
     } while (0)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
-template <int MAP>
+template <int MAP, int W16 = 0>
 __global__ __launch_bounds__(256) void shape4(const float* __restrict__ in, float* __restrict__ out, unsigned n_steps, long long out_pitch,
                                               unsigned* __restrict__ tickets) {
     extern __shared__ float s_dyn[];   // (occupancy knob only)
@@ -60,8 +63,14 @@ __global__ __launch_bounds__(256) void shape4(const float* __restrict__ in, floa
     v2f r[8];
     if (g < n_steps) {
         const v2f* src = reinterpret_cast<const v2f*>(in + ((long long)g * 4 + wave) * 512) + lane;
+        if (W16) {   // 16-byte loads: 1 KB per wave-instruction, four per frame
+            const v4f* s4 = reinterpret_cast<const v4f*>(in + ((long long)g * 4 + wave) * 512) + lane;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) r[m] = src[64 * m];
+            for (int m = 0; m < 4; ++m) { const v4f q = s4[64 * m]; r[2 * m] = v2f{q.x, q.y}; r[2 * m + 1] = v2f{q.z, q.w}; }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) r[m] = src[64 * m];
+        }
     }
     for (int it = 0; g < n_steps; ++it) {
         unsigned g_nn = g_next + nblk;
@@ -74,8 +83,14 @@ __global__ __launch_bounds__(256) void shape4(const float* __restrict__ in, floa
         for (int m = 0; m < 8; ++m) cur[m] = r[m];
         if (g_next < n_steps) {                   // next step's frame travels while this one is "transformed"
             const v2f* src = reinterpret_cast<const v2f*>(in + ((long long)g_next * 4 + wave) * 512) + lane;
+            if (W16) {
+                const v4f* s4 = reinterpret_cast<const v4f*>(in + ((long long)g_next * 4 + wave) * 512) + lane;
 #pragma unroll
-            for (int m = 0; m < 8; ++m) r[m] = src[64 * m];
+                for (int m = 0; m < 4; ++m) { const v4f q = s4[64 * m]; r[2 * m] = v2f{q.x, q.y}; r[2 * m + 1] = v2f{q.z, q.w}; }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) r[m] = src[64 * m];
+            }
         }
         float* dst = out + ((long long)g * 4 + wave) * out_pitch;
 #pragma unroll
@@ -115,7 +130,7 @@ int main(int argc, char** argv) {
     const int rounds = argc > 1 ? std::atoi(argv[1]) : 3;
     for (int round = 0; round < rounds; ++round)
         for (int ldskb : {29, 38}) {              // 5 / 4 workgroups per CU
-            for (int map = 0; map < 4; ++map)
+            for (int map = 0; map < 5; ++map)
                 for (int bpc : {4, 5, 8}) {
                     if (map == 3 && bpc == 8) continue;          // dynamic: resident workgroups only
                     if (bpc * ldskb > 160 && map == 3) continue;
@@ -128,6 +143,7 @@ int main(int argc, char** argv) {
                             case 0: hipLaunchKernelGGL(shape4<0>, dim3(grid), dim3(256), ldskb * 1024, 0, s, d, n_steps, pitch, tickets); break;
                             case 1: hipLaunchKernelGGL(shape4<1>, dim3(grid), dim3(256), ldskb * 1024, 0, s, d, n_steps, pitch, tickets); break;
                             case 2: hipLaunchKernelGGL(shape4<2>, dim3(grid), dim3(256), ldskb * 1024, 0, s, d, n_steps, pitch, tickets); break;
+                            case 4: hipLaunchKernelGGL((shape4<2, 1>), dim3(grid), dim3(256), ldskb * 1024, 0, s, d, n_steps, pitch, tickets); break;
                             default: hipLaunchKernelGGL(shape4<3>, dim3(grid), dim3(256), ldskb * 1024, 0, s, d, n_steps, pitch, tickets); break;
                         }
                     };
