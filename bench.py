@@ -598,7 +598,11 @@ def main():
 
     power = None
     if rank == 0 and not args.dry_run and world == 1 and not args.no_power:
-        power = power_report(torch, lib, one, run_step, units_per_batch * bpd * dps, algo_batch * bpd * dps, args.power_seconds, dev_index)
+        try:   # (a reported figure, never a reason to lose the bench line)
+            power = power_report(torch, lib, one, run_step, units_per_batch * bpd * dps, algo_batch * bpd * dps, args.power_seconds, dev_index)
+        except Exception as e:
+            power = {"error": f"{type(e).__name__}: {e}"[:200]}
+            torch.cuda.synchronize()
     if rank == 0 and not args.dry_run and world == 1 and not args.no_calibration:
         calibration = calibrate_copy(lib, torch, one)
     if rank == 0 and not args.dry_run and world == 1 and not args.no_parity:
