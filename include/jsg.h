@@ -40,8 +40,9 @@
 extern "C" {
 #endif
 
-#define JSG_ABI_VERSION 5   /* 3: + kernel-name query, launch pool, image scratch query, sharded set; 4: + strided image batches (round 3);
-                               5: + strided dB batches, exact-log mode, producer ring statistics (round 4) */
+#define JSG_ABI_VERSION 6   /* 3: + kernel-name query, launch pool, image scratch query, sharded set; 4: + strided image batches (round 3);
+                               5: + strided dB batches, exact-log mode, producer ring statistics (round 4);
+                               6: + lossless producer call, all-or-nothing sharded push, exact-log display path, tail plane, pair plan (round 5) */
 
 typedef enum jsg_status {
     JSG_OK = 0,
@@ -155,10 +156,19 @@ typedef struct jsg_stft_args {
                                 jsg_stft_kernel_name() tells which one a launch takes.  Other sizes: ignored */
     int32_t exact_log;       /* 0: 10*log10 on the hardware log unit (1 ulp, not specified bit for bit); 1: by the library's own float32
                                 routine (jadespectrogram_amd/csrc/jsg_exact_math.h: exponent + degree-9 polynomial, within 2 ulp of the
-                                reference's double log10): every dB value -- and so every palette index -- is then reproducible bit for
-                                bit on a CPU (oracle/jsg_mirror.c does).  The launch stores linear power and converts its columns in
-                                place with a second, elementwise kernel (one more read + write of the output); the dB launches only
-                                (jsg_stft_db_launch, _strided, _batches, the engine via jsg_set_exact_log).  (was: reserved) */
+                                reference's double log10): every dB value -- and so every palette index and ARGB pixel -- is then
+                                reproducible bit for bit on a CPU (oracle/jsg_mirror.c does).  A separate instantiation of the kernel
+                                whose epilogue calls the routine (16 instead of 3 vector instructions per value): every launch form takes
+                                it -- jsg_stft_db_launch, _strided, _batches, jsg_stft_image_launch(_strided) in both of its forms, the
+                                engine via jsg_set_exact_log.  (round 4: a second elementwise pass, dB launches only) */
+    int32_t reserved0;       /* 0 */
+    float* out_tail;         /* NULL: the reference's column layout, bin n/2 at out_db[col*out_pitch + n/2].  Otherwise: a dense plane of
+                                one float per ring column; bin n/2 of ring column col is written to out_tail[r*ring_width + col] (r = 0, or
+                                the channel in per-channel mode, or batch * planes + channel in a strided launch: rows x ring_width floats)
+                                and NOT into the column, whose pitch may then be n/2 floats (>= n/2): a column is exactly n/2 * 4 bytes of
+                                whole 128-byte lines and the 4-byte piece that opened one more line per column is gone (N = 1024: 16
+                                lines instead of 16 + 1/32).  Values are bit-identical to the reference layout.  dB launches only
+                                (jsg_stft_db_launch, _strided, _batches); must be NULL for the image launches */
 } jsg_stft_args;
 JSG_API int jsg_stft_db_launch(const jsg_plan* plan, const jsg_stft_args* args, void* stream);
 /* The kernel configuration jsg_stft_db_launch picks for these arguments on the current device, as text ("Cfg1024", "Cfg2048",
@@ -295,7 +305,11 @@ JSG_API int jsg_get_device(const jsg_engine* e);
  * whose sizes differ by at most one: entry i owns [first_channel[i], first_channel[i] + channel_count[i]) and gets no engine
  * (out[i] = NULL) when that run is empty.  The engines share nothing -- the path shards by independent channels, there is no
  * collective (a cross-GPU AbsMean is the one exchange: INTEGRATION.md C).  Configure every engine with the usual setters.
- * jsg_process_block_sharded hands every engine its run of the planar pointers (enqueue only); jsg_destroy_sharded frees the set. */
+ * jsg_process_block_sharded hands every engine its run of the planar pointers (enqueue only, wait-free) -- ALL OR NOTHING: if any
+ * engine would not take the block now (its queue is full, it is in a geometry change, or its worker met an error) NO engine gets it,
+ * every engine counts one dropped block and 1 is returned, so the rings of the shards keep the same position.  (A geometry setter of one
+ * engine racing with the call is the one case that can still leave the set uneven: the caller changes the geometry of ALL engines and
+ * every setter wipes the history, so it resynchronises there.)  jsg_destroy_sharded frees the set. */
 JSG_API int jsg_create_sharded(jsg_engine** out, int* first_channel, int* channel_count, const int* devices, int n_devices, int channels);
 JSG_API int jsg_process_block_sharded(jsg_engine* const* engines, const int* first_channel, int n_devices, const float* const* planar);
 JSG_API int jsg_destroy_sharded(jsg_engine** engines, int n_devices);
@@ -338,7 +352,15 @@ JSG_API int jsg_process_block(jsg_engine* e, const float* const* planar);
  * the FFT-size combo box): a block of another channel count or length than the engine's current one is dropped (returns 1)
  * instead of being read past its end.  0 = do not check that value. */
 JSG_API int jsg_process_block_n(jsg_engine* e, const float* const* planar, int channels, int n);
-/* blocks dropped by jsg_process_block(_n) since the engine was created */
+/* The LOSSLESS form for callers that are not bound to real time (a DAW's offline bounce -- juce::AudioProcessor::isNonRealtime() --,
+ * converters, test loops that push faster than the GPU takes blocks out): where jsg_process_block would drop a block because the ring is
+ * full, this call waits (yield, then 100 us sleeps) until a slot is free, at most timeout_ms milliseconds (< 0: no limit).  The reference
+ * never drops a block (Spectrogram.cpp:37-135 computes in place); this entry point keeps that property.  channels / n as in
+ * jsg_process_block_n (0 = not checked).  Returns 0 (queued), 1 (dropped and counted: geometry change in progress, geometry mismatch, or
+ * still full at the timeout), < 0 (error).  NOT for the audio thread of a live host. */
+JSG_API int jsg_process_block_wait(jsg_engine* e, const float* const* planar, int channels, int n, int timeout_ms);
+/* blocks that did not reach the ring since the engine was created: dropped by jsg_process_block(_n/_wait/_sharded), refused because of an
+ * earlier worker error, or discarded by the worker */
 JSG_API long long jsg_get_dropped_blocks(const jsg_engine* e);
 /* The same for n_blocks consecutive blocks in one launch: samples[c*pitch + i], i < n_blocks*n. */
 JSG_API int jsg_process_blocks(jsg_engine* e, const float* samples, int64_t pitch, int n_blocks);

@@ -60,7 +60,7 @@ def build_variant(name: str, hip_flags, verbose: bool = False) -> str:
             continue
         objs.append(o)
         cmd = [hipcc, "-std=c++17", "-O3", "-fPIC", "-c", s, "-o", o, "-I", os.path.join(ROOT, "include"),
-               f"--offload-arch={ARCH}"] + VISIBILITY + HIP_FLAGS + ([] if os.environ.get("JSG_NO_UNIT_FLAGS") else UNIT_FLAGS.get(src, [])) + list(hip_flags)
+               f"--offload-arch={ARCH}", "-DJSG_DEV_KNOBS"] + VISIBILITY + HIP_FLAGS + ([] if os.environ.get("JSG_NO_UNIT_FLAGS") else UNIT_FLAGS.get(src, [])) + list(hip_flags)
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
@@ -80,6 +80,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         force = True
     objs = []
     recompiled, relinked = [], False
+    cmds = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
@@ -94,7 +95,12 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
                 cmd += ["-ffp-contract=off", "-D__HIP_PLATFORM_AMD__"]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
-            subprocess.check_call(cmd)
+            cmds.append(cmd)
+    # the translation units are independent: compile them side by side (the two kernel units take about a minute each)
+    procs = [subprocess.Popen(c) for c in cmds]
+    failed = [c for c, p in zip(cmds, procs) if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
     if force or _stale(LIB, objs):
         relinked = True
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs

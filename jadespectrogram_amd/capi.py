@@ -39,7 +39,7 @@ class StftArgs(C.Structure):
                 ("n_frames", C.c_int64), ("out_db", C.c_void_p), ("out_pitch", C.c_int64),
                 ("out_channel_pitch", C.c_int64), ("ring_width", C.c_int32), ("ring_pos", C.c_int32),
                 ("linear_out", C.c_int32), ("blocks_per_cu", C.c_int32), ("in_samples", C.c_int64),
-                ("plan_select", C.c_int32), ("exact_log", C.c_int32)]
+                ("plan_select", C.c_int32), ("exact_log", C.c_int32), ("reserved0", C.c_int32), ("out_tail", C.c_void_p)]
 
 
 class ColormapArgs(C.Structure):
@@ -114,6 +114,7 @@ SIGNATURES = {
     "jsg_get_window": (C.c_int, [_P, _P, C.c_int]),
     "jsg_process_block": (C.c_int, [_P, C.POINTER(_P)]),
     "jsg_process_block_n": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int]),
+    "jsg_process_block_wait": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int, C.c_int]),
     "jsg_get_dropped_blocks": (C.c_longlong, [_P]),
     "jsg_process_blocks": (C.c_int, [_P, _P, C.c_int64, C.c_int]),
     "jsg_process_blocks_device": (C.c_int, [_P, _P, C.c_int64, C.c_int]),

@@ -33,14 +33,16 @@ struct BlockQueue {
     std::atomic<int> inflight{0};                // producer calls inside push()
     std::atomic<unsigned long long> dropped{0};
 
-    // 0: queued; 1: dropped (ring full, geometry change in progress, or the caller's geometry is not the queue's); -2: null pointer.
-    // ch_check / n_check > 0: the geometry the caller's pointers were sized for.
-    int push(const float* const* planar, int ch_check, int n_check) {
+    // 0: queued; 1: not taken, ring full; 2: not taken, geometry change in progress or the caller's geometry is not the queue's (also a
+    // queue whose last geometry change failed: no slots); -2: null pointer.  ch_check / n_check > 0: the geometry the caller's pointers
+    // were sized for.  `count_drop`: count a block that was not taken in `dropped` (the lossless caller retries a full ring instead).
+    int try_push(const float* const* planar, int ch_check, int n_check, bool count_drop) {
         inflight.fetch_add(1);                   // (sequentially consistent with cfg_gen: Dekker-style hand-shake with the setter)
         const unsigned g = cfg_gen.load();
         int rc = 0;
-        if (g & 1u) rc = 1;
-        else if ((ch_check > 0 && ch_check != channels) || (n_check > 0 && n_check != n)) rc = 1;
+        if (g & 1u) rc = 2;
+        else if (!mem || channels <= 0 || n <= 0) rc = 2;   // the last geometry change failed: closed until a setter succeeds
+        else if ((ch_check > 0 && ch_check != channels) || (n_check > 0 && n_check != n)) rc = 2;
         else {
             const unsigned long long h = head.load(std::memory_order_relaxed);
             if (h - tail.load(std::memory_order_acquire) >= (unsigned long long)kSlots) rc = 1;
@@ -57,9 +59,20 @@ struct BlockQueue {
                 }
             }
         }
-        if (rc == 1) dropped.fetch_add(1, std::memory_order_relaxed);
+        if (rc > 0 && count_drop) dropped.fetch_add(1, std::memory_order_relaxed);
         inflight.fetch_sub(1);
         return rc;
+    }
+    // the wait-free producer call: 0 queued, 1 dropped (and counted), -2 null pointer
+    int push(const float* const* planar, int ch_check, int n_check) {
+        const int rc = try_push(planar, ch_check, n_check, true);
+        return rc > 0 ? 1 : rc;
+    }
+    // would a push of this geometry be taken right now?  (single producer: free slots can only grow until its next push)
+    bool can_push(int ch_check, int n_check) const {
+        if ((cfg_gen.load() & 1u) || !mem || channels <= 0 || n <= 0) return false;
+        if ((ch_check > 0 && ch_check != channels) || (n_check > 0 && n_check != n)) return false;
+        return head.load(std::memory_order_relaxed) - tail.load(std::memory_order_acquire) < (unsigned long long)kSlots;
     }
 
     // consumer: the oldest block, if any (`current`: it was pushed under the geometry that is in force)

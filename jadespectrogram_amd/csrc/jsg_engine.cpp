@@ -247,6 +247,15 @@ int ensure_input_capacity(jsg_engine* e, int blocks, bool keep_tail) {
 // Spectrogram::buildmem (Spectrogram.cpp:213-238): geometry, -120 dB ring, zeroed input ring, counters.
 // Called with rd_mu and mu held.
 int buildmem(jsg_engine* e) {
+    // A changed slot geometry (channel count, FFT size: only the geometry setters and creation come here with one, inside a GeomEpoch
+    // -- no producer call is inside, the worker has drained the queue) CLOSES the producer's queue first: whatever fails below, the
+    // audio thread finds a queue without slots and drops its blocks (try_push) instead of copying into slots of the old size that the
+    // worker would then read with the new one.  The queue opens again at the end of a build that succeeded.
+    const bool slot_geometry_changed = e->q.channels != e->channels || e->q.n != e->n;
+    if (slot_geometry_changed) {
+        e->q.channels = 0;
+        e->q.n = 0;
+    }
     JSG_HIP(e, hipSetDevice(e->device));
     e->hop = jsg_feed_samples(e->feed_percent, e->n);
     if (e->hop <= 0) return e->fail(JSG_ERR_INVALID, "feed percentage gives a hop of 0 samples");
@@ -285,9 +294,9 @@ int buildmem(jsg_engine* e) {
         JSG_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->q.mem), slot * BlockQueue::kSlots * sizeof(float), hipHostMallocDefault));
         e->q.slot_floats = slot;
     }
-    e->q.channels = e->channels;
-    e->q.n = e->n;
     if (!e->ev_q) JSG_HIP(e, hipEventCreateWithFlags(&e->ev_q, hipEventDisableTiming));
+    e->q.channels = e->channels;   // the queue's geometry is published only together with slots of that size
+    e->q.n = e->n;
     e->mem_counter = 0;
     e->new_entry = kNewEntrySentinel;
     e->host_fixed_valid = false;
@@ -381,6 +390,7 @@ void drain_queue(jsg_engine* e) {
             }
         }
         if (copied) (void)hipEventSynchronize(e->ev_q);   // the DMA has read the slot (outside the state lock)
+        else e->q.dropped.fetch_add(1, std::memory_order_relaxed);   // discarded (an earlier error of the worker, or a stale geometry): not in the ring
         e->q.pop(t);
     }
 }
@@ -513,16 +523,37 @@ int jsg_create_sharded(jsg_engine** out, int* first_channel, int* channel_count,
     return JSG_OK;
 }
 
-// processSynchronBlock for the sharded set: every engine takes its own run of the planar channel pointers.  Enqueue only, like
-// jsg_process_block; the first failing engine's code is returned (its text: jsg_last_error(engine)).
+// processSynchronBlock for the sharded set: every engine takes its own run of the planar channel pointers.  ALL OR NOTHING: the rings
+// of the shards must advance together (a cross-GPU AbsMean, or per-channel columns shown side by side, rely on the same ring position on
+// every shard), so the call first asks every engine whether it would take a block now -- queue not full, no geometry change in progress,
+// no earlier worker error -- and pushes only if all of them would.  Otherwise NO engine gets the block, every engine counts one dropped
+// block, and 1 is returned (< 0: the first engine's stored error).  The check stays true until the push for everything the producer
+// thread can cause (single producer: slots only get freed in between); the one thing that can still come between is a geometry setter of
+// ONE engine from the message thread -- then the engines that took the block are ahead by one, the return value is that engine's 1, and
+// the caller has to resynchronise the set, which a geometry change of a sharded set needs anyway (every setter wipes the history:
+// buildmem).  Enqueue only, wait-free like jsg_process_block.
 int jsg_process_block_sharded(jsg_engine* const* engines, const int* first_channel, int n_devices, const float* const* planar) {
     if (!engines || !first_channel || n_devices <= 0 || !planar) return jsg_fail(JSG_ERR_INVALID, "jsg_process_block_sharded: bad argument");
+    bool all = true;
+    for (int i = 0; i < n_devices; ++i) {
+        if (!engines[i]) continue;
+        const int arc = engines[i]->async_rc.load(std::memory_order_acquire);
+        if (arc != 0) return arc;
+        if (!engines[i]->q.can_push(0, 0)) all = false;
+    }
+    if (!all) {
+        for (int i = 0; i < n_devices; ++i)
+            if (engines[i]) engines[i]->q.dropped.fetch_add(1, std::memory_order_relaxed);
+        return 1;
+    }
+    int worst = JSG_OK;
     for (int i = 0; i < n_devices; ++i) {
         if (!engines[i]) continue;
         const int rc = jsg_process_block(engines[i], planar + first_channel[i]);
-        if (rc != JSG_OK) return rc;
+        if (rc < 0) return rc;
+        if (rc > worst) worst = rc;
     }
-    return JSG_OK;
+    return worst;
 }
 
 int jsg_destroy_sharded(jsg_engine** engines, int n_devices) {
@@ -583,6 +614,7 @@ int jsg_destroy(jsg_engine* e) {
     } while (0)
 
 int jsg_set_samplerate(jsg_engine* e, float fs) {
+    GeomEpoch epoch(e);   // every rebuild is bracketed: a queue that an earlier failed geometry change left closed may be re-opened here
     JSG_LOCK_CONFIG(e);
     if (!(fs > 0.f)) return e->fail(JSG_ERR_INVALID, "sample rate must be positive");
     e->fs = fs;
@@ -617,6 +649,7 @@ int jsg_set_closest_fft_size_ms(jsg_engine* e, float ms) {
 }
 
 int jsg_set_memory_time_s(jsg_engine* e, float seconds) {
+    GeomEpoch epoch(e);   // every rebuild is bracketed: a queue that an earlier failed geometry change left closed may be re-opened here
     JSG_LOCK_CONFIG(e);
     if (!(seconds > 0.f)) return e->fail(JSG_ERR_INVALID, "memory time must be positive");
     e->memsize_s = seconds;
@@ -624,6 +657,7 @@ int jsg_set_memory_time_s(jsg_engine* e, float seconds) {
 }
 
 int jsg_set_feed_percent(jsg_engine* e, int feed) {
+    GeomEpoch epoch(e);   // every rebuild is bracketed: a queue that an earlier failed geometry change left closed may be re-opened here
     JSG_LOCK_CONFIG(e);
     switch (feed) {   // Spectrogram.cpp:191-209
         case JSG_FEED_100: e->feed_percent = 100.f; e->feedblocks = 1; break;
@@ -636,6 +670,7 @@ int jsg_set_feed_percent(jsg_engine* e, int feed) {
 }
 
 int jsg_set_feed_percent_ext(jsg_engine* e, float percent) {
+    GeomEpoch epoch(e);   // every rebuild is bracketed: a queue that an earlier failed geometry change left closed may be re-opened here
     JSG_LOCK_CONFIG(e);
     const int hop = jsg_feed_samples(percent, e->n);
     if (hop <= 0 || hop > e->n) return e->fail(JSG_ERR_INVALID, "feed percentage out of range");
@@ -669,6 +704,7 @@ int jsg_set_window_table(jsg_engine* e, const float* w, int n) {
 }
 
 int jsg_set_mix_mode(jsg_engine* e, int mode) {
+    GeomEpoch epoch(e);   // every rebuild is bracketed: a queue that an earlier failed geometry change left closed may be re-opened here
     JSG_LOCK_CONFIG(e);
     const bool known = (mode >= JSG_MIX_ABSMEAN && mode <= JSG_MIX_RIGHT) || mode == JSG_MIX_PER_CHANNEL;
     if (!known) return e->fail(JSG_ERR_INVALID, "unknown mix mode");
@@ -720,13 +756,45 @@ int jsg_process_block_n(jsg_engine* e, const float* const* planar, int channels,
     if (!e) return jsg_fail(JSG_ERR_INVALID, "null engine");
     if (!planar) return e->fail(JSG_ERR_INVALID, "null block");
     const int arc = e->async_rc.load(std::memory_order_acquire);
-    if (arc != 0) return arc;
+    if (arc != 0) {
+        e->q.dropped.fetch_add(1, std::memory_order_relaxed);   // not in the ring either
+        return arc;
+    }
     const int rc = e->q.push(planar, channels, n);
     if (rc < 0) return e->fail(JSG_ERR_INVALID, "null channel pointer");
     return rc;
 }
 
 int jsg_process_block(jsg_engine* e, const float* const* planar) { return jsg_process_block_n(e, planar, 0, 0); }
+
+// The LOSSLESS form for callers that are not bound to real time (a DAW's offline bounce -- juce::AudioProcessor::isNonRealtime() --,
+// file converters, test loops): where jsg_process_block would drop a block because the ring is full (the caller runs faster than the GPU
+// takes blocks out) this call WAITS -- yields, then sleeps 100 us at a time -- until a slot is free, for at most timeout_ms milliseconds
+// (< 0: no limit).  The reference never drops a block (processSynchronBlock computes in place, Spectrogram.cpp:37-135); this is the
+// entry point that keeps that property.  Returns 0 (queued), 1 (dropped and counted: geometry change in progress / geometry mismatch,
+// or still full at the timeout), < 0 (error).  NOT for the audio thread of a live host.
+int jsg_process_block_wait(jsg_engine* e, const float* const* planar, int channels, int n, int timeout_ms) {
+    if (!e) return jsg_fail(JSG_ERR_INVALID, "null engine");
+    if (!planar) return e->fail(JSG_ERR_INVALID, "null block");
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spins = 0;; ++spins) {
+        const int arc = e->async_rc.load(std::memory_order_acquire);
+        if (arc != 0) {
+            e->q.dropped.fetch_add(1, std::memory_order_relaxed);
+            return arc;
+        }
+        const int rc = e->q.try_push(planar, channels, n, false);
+        if (rc == 0) return 0;
+        if (rc < 0) return e->fail(JSG_ERR_INVALID, "null channel pointer");
+        const bool timed_out = timeout_ms >= 0 && std::chrono::steady_clock::now() - t0 >= std::chrono::milliseconds(timeout_ms);
+        if (rc == 2 || timed_out) {   // a geometry change wipes the history anyway: nothing to wait for
+            e->q.dropped.fetch_add(1, std::memory_order_relaxed);
+            return 1;
+        }
+        if (spins < 64) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+}
 
 long long jsg_get_dropped_blocks(const jsg_engine* e) { return e ? (long long)e->q.dropped.load(std::memory_order_relaxed) : JSG_ERR_INVALID; }
 

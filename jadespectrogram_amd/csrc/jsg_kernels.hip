@@ -14,6 +14,19 @@
 
 namespace jsg {
 
+// Development knobs (A/B switches read from the environment once per process) exist in VARIANT builds only (-DJSG_DEV_KNOBS:
+// jadespectrogram_amd/_build.py build_variant, tools/README.md).  The product library never reads the environment: inside a DAW process
+// an inherited variable would silently change which plan runs, and with it the last bits of the columns (jsg.h: plan_select).
+#ifdef JSG_DEV_KNOBS
+static int dev_knob_int(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
+static bool dev_knob_set(const char* name) { return getenv(name) != nullptr; }
+static bool dev_knob_is(const char* name, char first) { const char* e = getenv(name); return e && e[0] == first; }
+#else
+static constexpr int dev_knob_int(const char*) { return 0; }
+static constexpr bool dev_knob_set(const char*) { return false; }
+static constexpr bool dev_knob_is(const char*, char) { return false; }
+#endif
+
 static bool b_plan_fills_its_rounds(long long n_frames, int frames_per_workgroup, int n_cu) {
     const long long want = (n_frames + frames_per_workgroup - 1) / frames_per_workgroup;
     const long long rounds = (want + n_cu - 1) / n_cu;
@@ -137,20 +150,6 @@ __global__ __launch_bounds__(256) void db_from_power_kernel(const float* p, floa
         if (divisor != 1.0f) v = v / divisor;
         out[i] = exact_log ? jsg_exact_db(v) : to_db(v);
     }
-}
-
-// jsg_stft_args.exact_log: the columns a launch has just written as LINEAR mixed power become dB in place through jsg_exact_db (plain
-// float32 arithmetic shared with the CPU mirror, jsg_exact_math.h).  A separate elementwise pass on purpose: as a run-time branch
-// inside stft_db_kernel it moved the register allocation of every instantiation (three VGPRs more, spills in the index-out forms of
-// the 1024- and 4096-point plans), and the default path -- the hardware log unit -- must not pay for an opt-in mode.
-// grid (columns, rows): column i of the launch = ring column (ring_pos + i) % ring_w of row y (a batch, or a batch x channel plane)
-__global__ __launch_bounds__(256) void exact_db_columns_kernel(float* base, long long col_pitch, int height, int ring_w, int ring_pos,
-                                                               long long row_stride_a, int rows_a, long long row_stride_b) {
-    unsigned col = (unsigned)ring_pos + blockIdx.x;
-    if (col >= (unsigned)ring_w) col -= ring_w;
-    const unsigned ya = blockIdx.y % (unsigned)rows_a, yb = blockIdx.y / (unsigned)rows_a;   // (channel plane, batch)
-    float* p = base + (long long)ya * row_stride_a + (long long)yb * row_stride_b + (long long)col * col_pitch;
-    for (int k = threadIdx.x; k < height; k += 256) p[k] = jsg_exact_db(p[k]);
 }
 
 // roofline calibration (jsg_calib_copy_launch): the float4 streaming copy that reaches the most on an MI355X -- one thread per 16 bytes,
@@ -285,8 +284,8 @@ struct IndexOut {   // fused display path: where and how the palette indices of 
 // 2048 / 4096 points: does this launch take the "B" kernel?  (nc: channels combined into one column)
 static bool wants_plan_b(int n, const jsg_stft_args* g, int nc, int n_cu, long long frames_of_launch = -1) {   // (-1: g->n_frames)
     if (n != 2048 && n != 4096) return false;
-    static const int forced2048 = [] { const char* e = getenv("JSG_2048_PLAN"); return e ? atoi(e) : 0; }();   // development A/B: 2 = "B" | 3
-    static const int forced4096 = [] { const char* e = getenv("JSG_4096_PLAN"); return e ? atoi(e) : 0; }();
+    static const int forced2048 = dev_knob_int("JSG_2048_PLAN");   // variant builds only (JSG_DEV_KNOBS): 2 = "B" | 3
+    static const int forced4096 = dev_knob_int("JSG_4096_PLAN");
     const int forced = g->plan_select == 1 ? 3 : g->plan_select == 2 ? 2 : (n == 2048 ? forced2048 : forced4096);
     const int tpb_b = n == 2048 ? Cfg2048B::TPB : Cfg4096B::TPB;
     return forced == 2 || (forced != 3 && nc >= (n == 2048 ? k2048B_min_channels : k4096B_min_channels) &&
@@ -303,30 +302,12 @@ struct BatchSpec {   // jsg_stft_db_launch_strided: `n` batches of the geometry 
 static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const IndexOut* io, void* stream, const BatchSpec* bs = nullptr) {
     if (!plan || !g) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: null argument");
     if (g->n_frames == 0) return JSG_OK;
-    if (g->exact_log && !g->linear_out) {
-        // bit-reproducible dB: the kernel stores the mixed LINEAR power (the very float its own logarithm would have taken), then the
-        // columns of the launch are turned into dB in place by the shared float32 routine (exact_db_columns_kernel)
-        if (io) return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_image_launch: exact_log is a mode of the dB launches (jsg_stft_db_launch + jsg_colormap_launch)");
-        jsg_stft_args lin = *g;
-        lin.linear_out = 1;
-        lin.exact_log = 0;
-        const int rc = stft_launch_impl(plan, &lin, nullptr, stream, bs);
-        if (rc != JSG_OK) return rc;
-        const int planes = g->mix_mode == JSG_MIX_PER_CHANNEL ? g->channels : 1;
-        const long long rows = (long long)planes * (bs ? bs->n : 1);
-        if (rows > 65535) return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_db_launch: exact_log with more than 65535 channel planes x batches in one launch");
-        hipLaunchKernelGGL(exact_db_columns_kernel, dim3((unsigned)g->n_frames, (unsigned)rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g->out_db,
-                           (long long)g->out_pitch, plan->n / 2 + 1, g->ring_width, g->ring_pos, (long long)g->out_channel_pitch, planes,
-                           bs ? bs->out_stride : 0ll);
-        const hipError_t err = hipGetLastError();
-        if (err != hipSuccess) return jsg_fail_hip(err, "jsg_stft_db_launch (exact_log pass)");
-        return JSG_OK;
-    }
     const int H = plan->n / 2 + 1;
     if (!g->in || (!io && !g->out_db) || g->channels <= 0 || g->hop <= 0 || g->feedblocks <= 0 || g->n_frames < 0 ||
         g->first_frame < 0 || g->ring_width <= 0 || g->ring_pos < 0 || g->ring_pos >= g->ring_width ||
-        (!io && g->out_pitch < H))
+        (!io && g->out_pitch < H - (g->out_tail ? 1 : 0)))   // (with a tail plane a column is n/2 floats)
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_db_launch: bad geometry");
+    if (io && g->out_tail) return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch: out_tail belongs to the dB launches");
     if (io && !io->argb && (!io->idx || io->pitch < H || io->n_colors <= 0 || io->n_colors > 256 || g->linear_out))
         return jsg_fail(JSG_ERR_INVALID, "jsg_stft_image_launch: bad index scratch (needs n_colors <= 256, pitch >= n/2+1, dB mode)");
     if (io && io->argb && (!io->lut || io->n_colors <= 0 || io->n_colors > 256 || io->x_wrap <= 0 || io->x_first < 0 || g->linear_out ||
@@ -361,6 +342,8 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     ka.out_cpitch = g->out_channel_pitch;
     ka.ring_w = g->ring_width;
     ka.ring_pos = g->ring_pos;
+    ka.tail = io ? nullptr : g->out_tail;
+    ka.exact_log = g->exact_log ? 1 : 0;
     ka.tab = plan->d_tab;
     if (io) {
         ka.argb = io->argb;
@@ -378,9 +361,9 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
         ka.mult = io->mult;
         ka.n_colors = io->n_colors;
     }
-    static const int xcd_remap = getenv("JSG_NO_XCD_REMAP") ? 0 : 1;
+    static const int xcd_remap = dev_knob_set("JSG_NO_XCD_REMAP") ? 0 : 1;   // (variant builds only, as every dev_knob_*)
     ka.xcd_remap = xcd_remap;
-    static const int chunked = [] { const char* e = getenv("JSG_TRAVERSAL"); return (e && e[0] == 'c') ? 1 : 0; }();
+    static const int chunked = dev_knob_is("JSG_TRAVERSAL", 'c') ? 1 : 0;
     ka.chunked = chunked;
     ka.per_channel = 0;
     ka.c_begin = 0;
@@ -459,18 +442,14 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     }
     const int ny = (ka.per_channel && !bs) ? g->channels : 1;
     if (ny > 65535) return jsg_fail(JSG_ERR_UNSUPPORTED, "jsg_stft_db_launch: more than 65535 channels in per-channel mode");
-    static const int blocks_per_cu_env = [] {   // tuning knob (development): JSG_STFT_BLOCKS_PER_CU
-        const char* e = getenv("JSG_STFT_BLOCKS_PER_CU");
-        const int v = e ? atoi(e) : 0;
-        return v > 0 ? v : 0;
-    }();
+    static const int blocks_per_cu_env = std::max(0, dev_knob_int("JSG_STFT_BLOCKS_PER_CU"));
     // workgroups per CU of the grid; the rest of the frames is looped over.  The "B" plans hold one workgroup per CU: a grid of
     // exactly that many keeps the tables and the prefetch pipeline alive across a workgroup's frames (16 384 mono 4096-point
     // frames: 65 vs 79 us with a grid of 8 per CU); the other plans do best with more workgroups than are resident.
     const int bpc = g->blocks_per_cu > 0 ? g->blocks_per_cu : (blocks_per_cu_env > 0 ? blocks_per_cu_env : (plan_b ? 1 : 8));
     long long max_blocks = (long long)n_cu * bpc / ny;     // resident workgroups; the rest is looped over
     if (max_blocks < 64) max_blocks = 64;
-    static const int max_blocks_env = [] { const char* e = getenv("JSG_STFT_MAX_BLOCKS"); return e ? atoi(e) : 0; }();   // development
+    static const int max_blocks_env = dev_knob_int("JSG_STFT_MAX_BLOCKS");
     if (max_blocks_env > 0) max_blocks = max_blocks_env;
     // steps per workgroup first, then the smallest grid that covers the launch with that many: at most iters - 1 surplus steps in the
     // last round (a grid of max_blocks would leave up to max_blocks - 1 of them: 9 workgroups per CU for 30 720 steps measured
@@ -530,7 +509,7 @@ static int colormap_launch_impl(const jsg_colormap_args* g, const unsigned char*
 // points, and 4096 points when the launcher's choice for the launch is the one-wavefront-per-frame kernel ("B": automatic rule or
 // plan_select = 2) -- so the image is always that of jsg_stft_db_launch (same plan_select) + jsg_colormap_launch, bit for bit.
 static bool image_takes_one_kernel(const jsg_plan* plan, const jsg_stft_image_args* g, int n_images = 1) {
-    static const int two_kernels = getenv("JSG_IMAGE_TWO_KERNELS") ? 1 : 0;   // development A/B
+    static const int two_kernels = dev_knob_set("JSG_IMAGE_TWO_KERNELS") ? 1 : 0;
     const jsg_colormap_args& c = g->colour;
     if (two_kernels || !(plan->n == 1024 || plan->n == 4096) || !c.argb_out || c.index_out || c.n_colors <= 0 || c.n_colors > 256 ||
         !c.lut || c.x_wrap <= 0 || c.x_first < 0 || c.n_cols > c.x_wrap ||
@@ -641,7 +620,7 @@ static int strided_checks(const jsg_plan* plan, const jsg_stft_args* g, int n_ba
     if (n_batches > 1 && g->n_frames > 0) {
         if (g->channels <= 0 || g->ring_width <= 0 || g->out_pitch <= 0) return jsg_fail(JSG_ERR_INVALID, (std::string(who) + ": bad geometry").c_str());
         const long long ring_extent = (g->mix_mode == JSG_MIX_PER_CHANNEL ? (long long)(g->channels - 1) * g->out_channel_pitch : 0ll) +
-                                      (long long)(g->ring_width - 1) * g->out_pitch + plan->n / 2 + 1;
+                                      (long long)(g->ring_width - 1) * g->out_pitch + plan->n / 2 + (g->out_tail ? 0 : 1);
         if (out_batch_stride < ring_extent)
             return jsg_fail(JSG_ERR_INVALID, (std::string(who) + ": the rings of consecutive batches would overlap (out_batch_stride too small)").c_str());
         // the caller told us how long the channel rows are: consecutive batches may share samples (stride < row length: a long stream
@@ -674,6 +653,7 @@ int jsg_stft_db_launch_strided(const jsg_plan* plan, const jsg_stft_args* g, int
         jsg_stft_args one = *g;
         one.in = g->in + b0 * in_batch_stride;
         one.out_db = g->out_db ? g->out_db + b0 * out_batch_stride : nullptr;
+        if (g->out_tail) one.out_tail = g->out_tail + b0 * rows_per_batch * g->ring_width;   // (a dense plane: rows x ring_width)
         if (nb == 1) rc = jsg_stft_db_launch(plan, &one, stream);
         else {
             BatchSpec bs{nb, (long long)in_batch_stride, (long long)out_batch_stride};

@@ -342,12 +342,15 @@ struct StftKArgs {
     int c_begin, c_end;  // channel range that is combined into one column (mixed modes)
     int per_channel;     // one column per (channel, frame): blockIdx.y is the channel
     int linear;          // store linear power instead of dB
+    int exact_log;       // dB by jsg_exact_db (the XLOG instantiations) instead of v_log_f32
     float scale;         // AbsMean: 1/C (exact for power-of-two C); others: 1
     float divisor;       // AbsMean: float(C)
     int exact_div;       // C is not a power of two: divide (IEEE) instead of scaling
     unsigned first_frame, n_frames;
     float* out;
     long long out_pitch, out_cpitch;
+    float* tail;         // jsg_stft_args.out_tail: bin N/2 of ring column col of row r (batch x channel plane) goes to tail[r * ring_w + col]
+                         // instead of out[.. + N/2] -- the 4-byte piece that would otherwise open a 17th 128-byte line per column
     int ring_w, ring_pos;
     int iters;
     const float2* tab;   // lane tables (Cfg::TAB_* layout): window pairs, stage-1 / stage-2 twiddles, post-pass twiddles
@@ -463,7 +466,13 @@ __device__ __forceinline__ cf mix_combine2(cf acc, cf pw) {
 // every sample once.  Bit-identical, and level with or behind this form everywhere it was measured -- its sixteen lock-stepped waves
 // per CU transform at most 1.0e9 frames/s where the 24 independent ones of this form reach 1.6e9; tools/experiments/r04_staged_span_kernel.patch,
 // DESIGN.md section 6.)
-template <class C, int MIXOP, int OUTK = 0, int STREAM = 0>
+// XLOG (jsg_stft_args.exact_log): 0 = 10*log10 on the hardware log unit (v_log_f32: 1 ulp, not specified bit for bit); 1 = by jsg_exact_db of
+// jsg_exact_math.h (plain float32 arithmetic shared with the CPU mirror: the dB values, the palette indices and the ARGB pixels are then
+// reproducible bit for bit -- reference Spectrogram.cpp:107 feeding CColorpalette.h:32-47).  A separate INSTANTIATION, not a run-time
+// branch: as a branch (round 4) the routine moved the register allocation of every kernel (+3 VGPRs, spills in the index-out forms), so
+// the default path does not know it exists.  Round 4 ran it as a second elementwise pass over the columns of a launch (one more read and
+// write of the output, and no display path); since round 5 it sits in the epilogue of every output form.
+template <class C, int MIXOP, int OUTK = 0, int STREAM = 0, int XLOG = 0>
 __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_kernel(
     // Everything the table and frame loads depend on sits in the first 16 dwords of the kernel arguments: with
     // -amdgpu-kernarg-preload-count=16 those arrive in SGPRs with the wave, so the loads are issued without waiting for a
@@ -523,7 +532,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     // Grid-stride traversal: in iteration `it` the workgroups cover one contiguous window of gridDim.x*TPB frames that
     // sweeps through the stream (neighbouring workgroups touch neighbouring DRAM pages at the same time), instead
     // of every workgroup streaming through a private region (thousands of concurrent streams: 10-15 % less HBM
-    // bandwidth, see tools/copy_width_probe.py).  JSG_TRAVERSAL=chunk selects the old order (development A/B).
+    // bandwidth, see tools/copy_width_probe.py).  variant builds: JSG_TRAVERSAL=chunk selects the old order.
     const unsigned task_stride = a.chunked ? C::TPB : nblk * C::TPB;
     const unsigned task0 = (a.chunked ? lb * (unsigned)a.iters * C::TPB : lb * C::TPB) + slot0;   // first task of this wave
     // (STREAM: the channel of a per-channel row comes from the row number, see row_of; c0 / c1 then only give nc = 1)
@@ -933,6 +942,11 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                     accNy[f] *= a.scale;
                 }
                 if (!a.linear) {
+                    if constexpr (XLOG) {   // the shared float32 routine, value by value (16 full-rate instructions each)
+#pragma unroll
+                        for (int m = 0; m < P / 2; ++m) acc[f][m] = cf{jsg_exact_db(acc[f][m].x), jsg_exact_db(acc[f][m].y)};
+                        accNy[f] = jsg_exact_db(accNy[f]);
+                    } else {
 #pragma unroll
                     for (int m = 0; m < P / 2; ++m) {   // to_db() of both values of a pair: packed add and multiply around the two v_log
                         cf t = acc[f][m] + cf{1e-11f, 1e-11f};
@@ -940,6 +954,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                         acc[f][m] = t * cf{3.0102999566398120f, 3.0102999566398120f};
                     }
                     accNy[f] = to_db(accNy[f]);
+                    }
                 }
                 if constexpr (L == 32) {
                     // Two frames sit side by side in the wavefront (lanes 0-31 | 32-63), and register rho of a lane is bin
@@ -1064,11 +1079,28 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                     float* dstA = a.out + (long long)colA * a.out_pitch + cofs;
                     float* dstB = a.out + (long long)colB * a.out_pitch + cofs;
                     float* dst = a.out + (long long)col * a.out_pitch + cofs;
+                    // tail plane (jsg_stft_args.out_tail): bin N/2 -- the one value of a column that lies behind its sixteen (N = 1024)
+                    // whole 128-byte lines -- goes to a dense plane of one float per column instead; row = batch x channel plane
+                    float* tl_row = nullptr;
+                    if (a.tail) {
+                        unsigned trow = a.per_channel ? (unsigned)c0 : 0u;
+                        if constexpr (BAT) {
+                            unsigned col0_;
+                            group_of(it, trow, col0_);
+                        }
+                        tl_row = a.tail + (long long)trow * a.ring_w;
+                    }
 #pragma unroll
                     for (int rho = 0; rho < P / 2; ++rho) {
                         float* d = (L == 32 && (rho & 1)) ? dstB : dstA;
                         const int k = lw + LW * (L == 32 ? rho / 2 : rho);
                         __builtin_nontemporal_store(acc[f][rho].x, &d[k]);
+                        if ((L == 32 ? rho / 2 : rho) == 0 && tl_row) {   // this instruction's lane k == 0 holds bin M = N/2
+                            // a PLAIN store: the 4-byte pieces of the 32 columns that share a 128-byte line of the plane (neighbouring
+                            // workgroups, same XCD) meet in L2 and leave as one line
+                            if (k == 0) tl_row[(L == 32 && (rho & 1)) ? colB : colA] = acc[f][rho].y;
+                            else __builtin_nontemporal_store(acc[f][rho].y, &d[M - k]);
+                        } else
                         __builtin_nontemporal_store(acc[f][rho].y, &d[M - k]);
                     }
                     if (L <= 64 || ll == 0) __builtin_nontemporal_store(accNy[f], &dst[M / 2]);   // L <= 64: uniform over the frame's lanes
@@ -1137,7 +1169,7 @@ void fill_tables(std::vector<float2>& t, const float* window, double amp) {
 // Kernels that need more than 48 KB of dynamic LDS must be told so once per device.  jsg_plan_create does it for every
 // instantiation of the plan's size (so that the first launch may already sit inside a stream capture); the launch path
 // repeats the check for plans that are used on a device other than the one they were created on.
-template <class C, int MIXOP, int OUTK, int STREAM = 0>
+template <class C, int MIXOP, int OUTK, int STREAM = 0, int XLOG = 0>
 hipError_t ensure_lds_attr() {
     static std::atomic<bool> attr_done[64];   // set once per device; setting it twice from two threads is harmless
     constexpr int bytes = C::LDS_BYTES;
@@ -1146,7 +1178,7 @@ hipError_t ensure_lds_attr() {
     hipError_t err = hipGetDevice(&dev);
     if (err != hipSuccess) return err;
     if (dev >= 0 && dev < 64 && !attr_done[dev].load(std::memory_order_acquire)) {
-        err = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_db_kernel<C, MIXOP, OUTK, STREAM>),
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_db_kernel<C, MIXOP, OUTK, STREAM, XLOG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (err != hipSuccess) return err;
         attr_done[dev].store(true, std::memory_order_release);
@@ -1161,37 +1193,49 @@ constexpr bool image_ok = C::L == 64 && C::FPW == 1 && C::TPB == 8 && C::WPB == 
 template <class C>
 constexpr bool image_only = std::is_same<C, Cfg1024I>::value;
 
-template <class C>
-hipError_t ensure_lds_attrs_of_plan() {
+// every instantiation of a plan that can be launched: (MIXOP, OUTK, STREAM) x the two logarithms
+template <class C, int XLOG>
+hipError_t ensure_lds_attrs_of_plan_x() {
     if constexpr (image_only<C>) {
-        hipError_t e = ensure_lds_attr<C, 0, 2>();
-        if (e == hipSuccess) e = ensure_lds_attr<C, 3, 2>();
+        hipError_t e = ensure_lds_attr<C, 0, 2, 0, XLOG>();
+        if (e == hipSuccess) e = ensure_lds_attr<C, 3, 2, 0, XLOG>();
         return e;
     } else {
-    hipError_t e = ensure_lds_attr<C, 0, 0>();
-    if (e == hipSuccess) e = ensure_lds_attr<C, 1, 0>();
-    if (e == hipSuccess) e = ensure_lds_attr<C, 2, 0>();
-    if (e == hipSuccess) e = ensure_lds_attr<C, 3, 0>();
-    if (e == hipSuccess) e = ensure_lds_attr<C, 0, 1>();
-    if (e == hipSuccess) e = ensure_lds_attr<C, 3, 1>();
-    if (e == hipSuccess) e = ensure_lds_attr<C, 0, 0, 1>();
-    if (e == hipSuccess) e = ensure_lds_attr<C, 3, 0, 1>();
+    hipError_t e = ensure_lds_attr<C, 0, 0, 0, XLOG>();
+    if (e == hipSuccess) e = ensure_lds_attr<C, 1, 0, 0, XLOG>();
+    if (e == hipSuccess) e = ensure_lds_attr<C, 2, 0, 0, XLOG>();
+    if (e == hipSuccess) e = ensure_lds_attr<C, 3, 0, 0, XLOG>();
+    if (e == hipSuccess) e = ensure_lds_attr<C, 0, 1, 0, XLOG>();
+    if (e == hipSuccess) e = ensure_lds_attr<C, 3, 1, 0, XLOG>();
+    if (e == hipSuccess) e = ensure_lds_attr<C, 0, 0, 1, XLOG>();
+    if (e == hipSuccess) e = ensure_lds_attr<C, 3, 0, 1, XLOG>();
     if constexpr (image_ok<C>) {
-        if (e == hipSuccess) e = ensure_lds_attr<C, 0, 2>();
-        if (e == hipSuccess) e = ensure_lds_attr<C, 3, 2>();
+        if (e == hipSuccess) e = ensure_lds_attr<C, 0, 2, 0, XLOG>();
+        if (e == hipSuccess) e = ensure_lds_attr<C, 3, 2, 0, XLOG>();
     }
     return e;
     }
 }
+template <class C>
+hipError_t ensure_lds_attrs_of_plan() {
+    hipError_t e = ensure_lds_attrs_of_plan_x<C, 0>();
+    if (e == hipSuccess) e = ensure_lds_attrs_of_plan_x<C, 1>();
+    return e;
+}
 
 template <class C, int MIXOP, int OUTK = 0, int STREAM = 0>
 hipError_t launch_stft_mix(const StftKArgs& ka, dim3 grid, hipStream_t s) {
-    hipError_t err = ensure_lds_attr<C, MIXOP, OUTK, STREAM>();
+    const bool xlog = ka.exact_log && !ka.linear;   // (linear power has no logarithm: one instantiation serves both)
+    hipError_t err = xlog ? ensure_lds_attr<C, MIXOP, OUTK, STREAM, 1>() : ensure_lds_attr<C, MIXOP, OUTK, STREAM, 0>();
     if (err != hipSuccess) return err;
     const int flags = (ka.regular ? 1 : 0) | (ka.per_channel ? 2 : 0) | (ka.xcd_remap ? 4 : 0) | (ka.chunked ? 8 : 0);
     constexpr int lds = C::LDS_BYTES;
-    hipLaunchKernelGGL((stft_db_kernel<C, MIXOP, OUTK, STREAM>), grid, dim3(C::WPB * 64), lds, s, ka.in, ka.in_pitch, ka.tab, ka.n_frames,
-                       ka.first_frame, ka.hop, flags, unsigned(ka.c_begin) | unsigned(ka.c_end) << 16, ka.iters, grid.x, ka.feedblocks, ka);
+    if (xlog)
+        hipLaunchKernelGGL((stft_db_kernel<C, MIXOP, OUTK, STREAM, 1>), grid, dim3(C::WPB * 64), lds, s, ka.in, ka.in_pitch, ka.tab, ka.n_frames,
+                           ka.first_frame, ka.hop, flags, unsigned(ka.c_begin) | unsigned(ka.c_end) << 16, ka.iters, grid.x, ka.feedblocks, ka);
+    else
+        hipLaunchKernelGGL((stft_db_kernel<C, MIXOP, OUTK, STREAM, 0>), grid, dim3(C::WPB * 64), lds, s, ka.in, ka.in_pitch, ka.tab, ka.n_frames,
+                           ka.first_frame, ka.hop, flags, unsigned(ka.c_begin) | unsigned(ka.c_end) << 16, ka.iters, grid.x, ka.feedblocks, ka);
     return hipGetLastError();
 }
 

@@ -55,9 +55,20 @@ public:
         const size_t ch = data.size();
         if (ch == 0 || ch > m_ptrs.size()) return JSG_ERR_SIZE_MISMATCH;   // (m_ptrs is sized on the message thread: channelsPrepared)
         for (size_t c = 0; c < ch; ++c) m_ptrs[c] = data[c].data();
+        // An offline bounce (setNonRealtime(true)) may run faster than the GPU takes blocks out: there the call waits for a free slot
+        // instead of dropping -- the reference never loses a block (Spectrogram.cpp:37-135).
+        if (m_nonRealtime.load(std::memory_order_relaxed))
+            return jsg_process_block_wait(m_engine.get(), m_ptrs.data(), int(ch), int(data[0].size()), m_nonRealtimeTimeoutMs);
         return jsg_process_block_n(m_engine.get(), m_ptrs.data(), int(ch), int(data[0].size()));
     }
     long long droppedBlocks() const { return jsg_get_dropped_blocks(m_engine.get()); }   // blocks the engine did not take (see above)
+    // Mirror of juce::AudioProcessor::setNonRealtime: the processor forwards its own flag (prepareToPlay / processBlock:
+    // m_spectrogram.setNonRealtime(isNonRealtime())).  false (default): wait-free and lossy when the ring is full (a live host);
+    // true: lossless, the call may wait up to timeoutMs (< 0: no limit) for the engine's worker.
+    void setNonRealtime(bool nonRealtime, int timeoutMs = -1) {
+        m_nonRealtimeTimeoutMs = timeoutMs;
+        m_nonRealtime.store(nonRealtime, std::memory_order_relaxed);
+    }
     // Spectrogram::prepareParameter (reference Spectrogram.cpp:25-35): remember where the four display parameters live.
     // Nothing on the GPU depends on them; the IDs and defaults are those of reference Spectrogram.h:22-58
     // (frequencies are log-Hz, colour limits g_minColorVal / g_maxColorVal = -50 / +50 dB, PlugInGUISettings.h:37-38).
@@ -141,6 +152,8 @@ private:
         return false;
     }
     std::unique_ptr<jsg_engine, Deleter> m_engine;
+    std::atomic<bool> m_nonRealtime{false};
+    int m_nonRealtimeTimeoutMs = -1;
     std::vector<const float*> m_ptrs;
     std::vector<float*> m_rows;
     std::string m_lastError;

@@ -110,14 +110,28 @@ class Spectrogram:
         self._c(lib().jsg_get_window(self._h, w.ctypes.data, w.size))
         return w
 
-    def processSynchronBlock(self, data, midi=None) -> int:
-        """data: [channels][fft size] float32 (reference: vector<vector<float>>&, Spectrogram.cpp:37)."""
+    def processSynchronBlock(self, data, midi=None, realtime: bool = False, timeout_ms: int = 10000) -> int:
+        """data: [channels][fft size] float32 (reference: vector<vector<float>>&, Spectrogram.cpp:37).
+
+        A Python caller is not an audio thread, so the default is the LOSSLESS entry point (jsg_process_block_wait): like the reference,
+        no block is ever lost -- when the engine's 64-slot ring is full the call waits for the worker.  A block that still cannot be
+        queued (geometry change in progress, timeout) raises instead of vanishing.  realtime=True: the wait-free call of a live host
+        (jsg_process_block), which DROPS when the ring is full and returns 1; droppedBlocks() counts them."""
         data = np.ascontiguousarray(data, dtype=np.float32)
         n, ch = self.getFFTSize(), self.getChannels()
         if data.shape != (ch, n):
             raise JsgError(capi.JSG_ERR_SIZE_MISMATCH, f"block must be [{ch}][{n}], got {data.shape}")
         ptrs = (C.c_void_p * ch)(*[data[c].ctypes.data for c in range(ch)])
-        return self._c(lib().jsg_process_block(self._h, ptrs))
+        if realtime:
+            return self._c(lib().jsg_process_block(self._h, ptrs))
+        rc = self._c(lib().jsg_process_block_wait(self._h, ptrs, ch, n, int(timeout_ms)))
+        if rc == 1:
+            raise JsgError(1, "processSynchronBlock: the block was dropped (geometry change in progress, or the ring stayed full "
+                              f"for {timeout_ms} ms); pass realtime=True to get the wait-free, lossy call of a live host")
+        return rc
+
+    def droppedBlocks(self) -> int:
+        return int(lib().jsg_get_dropped_blocks(self._h))
 
     def processBlocks(self, samples) -> int:
         """samples: [channels][K * fft size]; the same as K processSynchronBlock calls, one kernel launch."""
@@ -304,7 +318,7 @@ def stft_db_strided(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, stream:
 
 
 def stft_db_strided_kernel_name(plan: Plan, d_in, hop: int, n_frames: int, d_out, **kw) -> str:
-    """The kernel a strided launch takes: "Cfg1024S" (staged persistent form), else as stft_kernel_name for the total size."""
+    """The kernel a strided launch takes: as stft_kernel_name, judged by the frames of the whole launch."""
     a, k, s_in, _ = _strided_args(plan, d_in, hop, n_frames, d_out, **kw)
     buf = C.create_string_buffer(32)
     check(lib().jsg_stft_db_strided_kernel_name(plan._p, C.byref(a), k, s_in, buf, 32))
@@ -321,11 +335,13 @@ def stft_kernel_name(plan: Plan, d_in, hop: int, n_frames: int, d_out, **kw) -> 
 
 def _stft_args(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: int | None = None, mix_mode: int = 0,
                first_frame: int = 0, ring_pos: int = 0, linear_out: bool = False, blocks_per_cu: int = 0, plan_select: int = 0,
-               exact_log: bool = False):
+               exact_log: bool = False, d_tail=None):
+    """d_tail (jsg_stft_args.out_tail): float32 CUDA tensor of rows x W floats (rows = 1, or channels in per-channel mode, times the batches
+    of a strided launch), contiguous -- bin n/2 of every column goes there and a column of d_out is then n/2 floats."""
     import torch
     assert d_in.is_cuda and d_in.dtype == torch.float32 and d_in.dim() == 2 and d_in.stride(1) == 1
     assert d_out.is_cuda and d_out.dtype == torch.float32 and d_out.stride(-1) == 1
-    H = plan.n // 2 + 1
+    H = plan.n // 2 + 1 - (1 if d_tail is not None else 0)
     if d_out.shape[-1] < H:
         raise JsgError(capi.JSG_ERR_INVALID, f"output rows hold {d_out.shape[-1]} floats, a column needs {H}")
     if mix_mode == capi.MIX_PER_CHANNEL and (d_out.dim() != 3 or d_out.shape[0] != d_in.shape[0]):
@@ -349,6 +365,9 @@ def _stft_args(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: 
     a.blocks_per_cu = int(blocks_per_cu)
     a.exact_log = int(bool(exact_log))     # dB by the shared float32 routine (bit-reproducible on a CPU) instead of v_log_f32
     a.plan_select = int(plan_select)       # 0 automatic, 1 small-workgroup kernel, 2 "B" kernel (2048 / 4096 points)
+    if d_tail is not None:
+        assert d_tail.is_cuda and d_tail.dtype == torch.float32 and d_tail.is_contiguous() and d_tail.shape[-1] == d_out.shape[-2]
+        a.out_tail = d_tail.data_ptr()
     return a
 
 

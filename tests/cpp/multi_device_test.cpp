@@ -110,8 +110,50 @@ int main(int argc, char** argv) {
         api_diff += pos != pos_ref;
         api_diff += std::memcmp(got.data(), ref.data() + size_t(sfirst[size_t(s)]) * W * H, got.size() * sizeof(float)) != 0;
     }
+    // A FULL ring: push far more blocks than the queues have slots, without a pause.  jsg_process_block_sharded is all or
+    // nothing -- a block is taken by every engine or by none -- so after any number of drops all shards have taken the same blocks: same
+    // dropped count, same ring position, and every shard's columns are those of its channels in ONE engine fed the accepted blocks only.
+    long long storm_dropped = 0;
+    size_t storm_diff = 0;
+    {
+        const int storm = 600;
+        std::vector<unsigned char> taken(static_cast<size_t>(storm), 0);
+        std::vector<long long> before(ns, 0);
+        for (int s = 0; s < shards; ++s)
+            if (set[size_t(s)]) before[size_t(s)] = jsg_get_dropped_blocks(set[size_t(s)]);
+        for (int b = 0; b < storm; ++b) {
+            for (int c = 0; c < C; ++c) all[size_t(c)] = x.data() + size_t(c) * blocks * N + size_t(b % blocks) * N;
+            const int rc = jsg_process_block_sharded(set.data(), sfirst.data(), shards, all.data());
+            if (rc < 0) { std::fprintf(stderr, "storm push -> %d\n", rc); return 2; }
+            taken[size_t(b)] = rc == 0;
+            storm_dropped += rc == 1;
+        }
+        // the reference run: one engine, only the accepted blocks, in order, behind the 12 blocks it already holds
+        std::vector<float> acc;
+        int n_acc = 0;
+        for (int b = 0; b < storm; ++b) n_acc += taken[size_t(b)];
+        acc.resize(size_t(C) * size_t(std::max(1, n_acc)) * N);
+        for (int c = 0; c < C; ++c) {
+            int k = 0;
+            for (int b = 0; b < storm; ++b)
+                if (taken[size_t(b)]) std::memcpy(&acc[(size_t(c) * n_acc + k++) * N], x.data() + size_t(c) * blocks * N + size_t(b % blocks) * N, N * sizeof(float));
+        }
+        if (n_acc > 0) CK(jsg_process_blocks(whole, acc.data(), int64_t(n_acc) * N, n_acc));
+        CK(jsg_peek_mem(whole, ref.data(), C * W, &pos_ref));
+        for (int s = 0; s < shards; ++s) {
+            if (!set[size_t(s)]) continue;
+            storm_diff += jsg_get_dropped_blocks(set[size_t(s)]) - before[size_t(s)] != storm_dropped;
+            std::vector<float> got(size_t(scount[size_t(s)]) * W * H);
+            int pos = -1;
+            CK(jsg_peek_mem(set[size_t(s)], got.data(), scount[size_t(s)] * W, &pos));
+            storm_diff += pos != pos_ref;
+            storm_diff += std::memcmp(got.data(), ref.data() + size_t(sfirst[size_t(s)]) * W * H, got.size() * sizeof(float)) != 0;
+        }
+    }
     CK(jsg_destroy_sharded(set.data(), shards));
     CK(jsg_destroy(whole));
+    api_diff += storm_diff;
+    std::printf("{\"storm_blocks\": 600, \"storm_dropped_on_every_shard\": %lld, \"storm_shards_out_of_step\": %zu}\n", storm_dropped, storm_diff);
     std::printf("{\"devices\": %d, \"shards\": %d, \"channels\": %d, \"columns\": %d, \"shards_differing\": %zu, \"pos_mismatch\": %d, \"sharded_api_differing\": %zu}\n", ndev,
                 shards, C, 2 * blocks, diff, pos_bad, api_diff);
     return diff == 0 && pos_bad == 0 && api_diff == 0 ? 0 : 1;

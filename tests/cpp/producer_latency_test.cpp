@@ -8,6 +8,8 @@
 // batch, undisturbed.  Prints one JSON line; the pytest wrapper asserts the bounds.
 #include <pthread.h>
 #include <sched.h>
+#include <sys/resource.h>
+#include <time.h>
 
 #include <algorithm>
 #include <atomic>
@@ -90,17 +92,57 @@ int main(int argc, char** argv) {
             (void)pthread_setaffinity_np(pthread_self(), sizeof mine, &mine);
         }
     }
-    std::vector<double> lat;
+    // Attribution of the tail: beside the wall-clock time of every call, the CPU time THIS THREAD spent in it
+    // (CLOCK_THREAD_CPUTIME_ID: stands still while the thread is descheduled) and the thread's involuntary context switches
+    // (getrusage(RUSAGE_THREAD).ru_nivcsw) around it.  A call that is long on the wall clock but short in thread-CPU time was taken off its
+    // core by the host's scheduler; a call that is long in thread-CPU time would be the library's own doing.
+    auto thread_cpu_us = [] {
+        timespec ts;
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+        return double(ts.tv_sec) * 1e6 + double(ts.tv_nsec) * 1e-3;
+    };
+    auto nivcsw = [] {
+        rusage ru;
+        getrusage(RUSAGE_THREAD, &ru);
+        return ru.ru_nivcsw;
+    };
+    std::vector<double> lat, cpu;
+    std::vector<unsigned char> switched;
     lat.reserve(size_t(blocks));
+    cpu.reserve(size_t(blocks));
+    switched.reserve(size_t(blocks));
+    const long nivcsw_before = nivcsw();
     for (int b = 0; b < blocks; ++b) {
         const float* ptrs[2] = {x.data() + size_t(b % period) * N, x.data() + chan_pitch + size_t(b % period) * N};
+        const long sw0 = nivcsw();
+        const double c0 = thread_cpu_us();
         const auto t0 = std::chrono::steady_clock::now();
         const int rc = jsg_process_block(live, ptrs);
         const auto t1 = std::chrono::steady_clock::now();
+        const double c1 = thread_cpu_us();
+        const long sw1 = nivcsw();
         if (rc < 0) { std::fprintf(stderr, "process_block: %s\n", jsg_last_error(live)); stop = true; consumer.join(); return 2; }
         lat.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
+        cpu.push_back(c1 - c0);
+        switched.push_back(sw1 != sw0);
         if (pace_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(pace_us));
     }
+    const long nivcsw_total = nivcsw() - nivcsw_before;
+    // long calls (wall clock > 50 us): how many coincide with an involuntary switch, how many are long in thread-CPU time as well
+    size_t long_calls = 0, long_with_switch = 0, long_cpu_over_50 = 0, cpu_over_50 = 0;
+    double cpu_max = 0.0, cpu_max_of_long = 0.0;
+    for (size_t i = 1; i < lat.size(); ++i) {   // (the first call pays the page faults of the fresh ring: reported on its own)
+        cpu_max = std::max(cpu_max, cpu[i]);
+        cpu_over_50 += cpu[i] > 50.0;
+        if (lat[i] > 50.0) {
+            ++long_calls;
+            long_with_switch += switched[i];
+            long_cpu_over_50 += cpu[i] > 50.0;
+            cpu_max_of_long = std::max(cpu_max_of_long, cpu[i]);
+        }
+    }
+    std::vector<double> cpu_sorted(cpu);
+    std::sort(cpu_sorted.begin(), cpu_sorted.end());
     stop = true;
     consumer.join();
     if (reader_rc.load() < 0) { std::fprintf(stderr, "reader failed: %s\n", jsg_last_error(live)); return 2; }
@@ -135,8 +177,13 @@ int main(int argc, char** argv) {
     for (double v : lat) over50 += v > 50.0;
     std::printf("{\"blocks\": %d, \"W\": %d, \"H\": %d, \"reads\": %ld, \"p50_us\": %.2f, \"p99_us\": %.2f, \"p9999_us\": %.2f, \"max_us\": %.1f, \"first_call_us\": %.1f, "
                 "\"max_after_first_us\": %.1f, \"worst_call\": %zu, \"calls_over_50us\": %zu, \"dropped_blocks\": %lld, "
-                "\"pos_live\": %d, \"pos_batch\": %d, \"differing_floats\": %zu, \"differing_pixels\": %zu}\n",
-                blocks, W, H, reads.load(), pct(0.5), pct(0.99), pct(0.9999), lat.back(), first_us, max_after_first, worst_at, over50, dropped, pa, pr, diff_floats, diff_px);
+                "\"pos_live\": %d, \"pos_batch\": %d, \"differing_floats\": %zu, \"differing_pixels\": %zu, "
+                "\"thread_cpu_p50_us\": %.2f, \"thread_cpu_p9999_us\": %.2f, \"thread_cpu_max_after_first_us\": %.1f, \"thread_cpu_calls_over_50us\": %zu, "
+                "\"long_wall_calls_after_first\": %zu, \"long_wall_calls_with_involuntary_switch\": %zu, \"long_wall_calls_long_in_thread_cpu_too\": %zu, "
+                "\"thread_cpu_max_of_long_wall_calls_us\": %.1f, \"involuntary_switches_total\": %ld}\n",
+                blocks, W, H, reads.load(), pct(0.5), pct(0.99), pct(0.9999), lat.back(), first_us, max_after_first, worst_at, over50, dropped, pa, pr, diff_floats, diff_px,
+                cpu_sorted[size_t(0.5 * double(cpu_sorted.size() - 1))], cpu_sorted[size_t(0.9999 * double(cpu_sorted.size() - 1))], cpu_max, cpu_over_50,
+                long_calls, long_with_switch, long_cpu_over_50, cpu_max_of_long, nivcsw_total);
     jsg_destroy(live);
     jsg_destroy(batch);
     return 0;

@@ -190,6 +190,14 @@ def test_producer_is_wait_free_under_a_reading_consumer(jsg):
     # other tenants of the host, and nothing in the call itself can wait.  A producer that waited for even one of the consumer's
     # 15 MB reads per hundred calls would put ONE PERCENT of the calls beyond 50 us; the guard sits at 0.2 %.
     assert info["calls_over_50us"] <= 200 and info["p9999_us"] < 2000.0, info
+    # ... and since round 5 the attribution is measured, not argued: the CPU time the producer THREAD spends inside a
+    # call (CLOCK_THREAD_CPUTIME_ID stands still while the thread is off its core) stays below 50 us for EVERY call after the first (the
+    # first one pays the page faults of the fresh page-locked ring), however long the wall clock says the call took; the report also
+    # counts how many of the long wall-clock calls coincide with an involuntary context switch of the thread (getrusage(RUSAGE_THREAD)).
+    # (three calls of grace: on kernels without IRQ time accounting an interrupt handler that runs on the producer's core is charged to
+    # the thread that happened to be running)
+    assert info["thread_cpu_calls_over_50us"] <= 3 and info["thread_cpu_p9999_us"] < 50.0, info
+    assert info["long_wall_calls_long_in_thread_cpu_too"] <= 3, info
 
 
 @pytest.mark.gpu
@@ -228,6 +236,10 @@ def test_several_engines_from_one_host_process(jsg, shards):
     info = json.loads(r.stdout.strip().splitlines()[-1])
     assert info["shards"] == shards and info["shards_differing"] == 0 and info["pos_mismatch"] == 0 and info["columns"] == 24
     assert info["sharded_api_differing"] == 0      # jsg_create_sharded / jsg_process_block_sharded: the same shards, the same bits
+    # 600 blocks pushed without a pause into 64-slot queues -- jsg_process_block_sharded is all or nothing, so whatever was
+    # dropped was dropped on EVERY shard and the rings stay in step (same position, same columns as one engine fed the accepted blocks)
+    storm = json.loads(r.stdout.strip().splitlines()[-2])
+    assert storm["storm_shards_out_of_step"] == 0 and storm["storm_dropped_on_every_shard"] >= 0, storm
 
 
 def _build_offline_render_example(jsg):

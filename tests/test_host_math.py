@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol(jsg):
     for name in sorted(declared):
         assert hasattr(lib, name), f"libjsg.so does not export {name}"
     assert declared == set(jsg.capi.SIGNATURES), declared ^ set(jsg.capi.SIGNATURES)
-    assert lib.jsg_abi_version() == 5
+    assert lib.jsg_abi_version() == 6
 
 
 def test_windows_bit_exact_vs_oracle(jsg, oracle):
