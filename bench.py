@@ -419,6 +419,9 @@ def main():
     ap.add_argument("--mode", choices=("strided", "single"), default="strided",
                     help="strided: one dispatch covers all batches of the rotation (default); single: one dispatch per batch, in order")
     ap.add_argument("--blocks-per-cu", type=int, default=0, help="workgroups per CU of a dispatch (0: the library's choice)")
+    ap.add_argument("--layout", choices=("auto", "tail", "reference"), default="auto",
+                    help="dB column layout of the timed dispatches: reference = bin n/2 inline (pitch n/2+1 rounded up to 32 floats); tail = "
+                         "jsg_stft_args.out_tail: columns of exactly n/2 floats + a dense plane of bin n/2 (same values; auto: tail for c2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the `parity` block (the profile scripts: its few launches would mix into the tracer's averages)")
     ap.add_argument("--no-boundary", action="store_true", help="skip the `boundary` block (jsg_process_block latency, PCIe-inclusive rate)")
@@ -499,9 +502,11 @@ def main():
         win = jsg.window(jsg.capi.WIN_HANN, n)
         plan = jsg.Plan(n, win)
         n_samples = (F * hop + (n - hop) + 3) // 4 * 4
-        pitch = (H + 31) // 32 * 32
+        use_tail = (not c["colour"]) and (args.layout == "tail" or (args.layout == "auto" and args.config == "c2"))
+        ref_pitch = (H + 31) // 32 * 32
+        pitch = n // 2 if use_tail else ref_pitch
         img_pitch = (F + 31) // 32 * 32
-        per_batch = C * n_samples * 4 + (H * img_pitch * 4 if c["colour"] else F * pitch * 4)
+        per_batch = C * n_samples * 4 + (H * img_pitch * 4 if c["colour"] else F * pitch * 4 + (F * 4 if use_tail else 0))
         if not args.nbuf and abs(nbuf * per_batch - ROTATION_BYTES) > 0.25 * ROTATION_BYTES:   # (a changed geometry: keep ~1 GB)
             nbuf = max(2, int(ROTATION_BYTES // per_batch) + 1)
             bpd = nbuf if strided else 1
@@ -511,6 +516,7 @@ def main():
             d_in[b].copy_(torch.from_numpy(np.ascontiguousarray(base[:, b * 64:b * 64 + n_samples])))
         d_img = torch.zeros((nbuf, H, img_pitch), dtype=torch.int32, device="cuda") if c["colour"] else None
         d_out = None if c["colour"] else torch.empty((nbuf, F, pitch), dtype=torch.float32, device="cuda")
+        d_tail = torch.empty((nbuf, 1, F), dtype=torch.float32, device="cuda") if use_tail else None
         d_lut = torch.from_numpy(jsg.colormap_lut(256, jsg.capi.CM_JADE)).cuda() if c["colour"] else None
         mixk = dict(feedblocks=fb, mix_mode=jsg.capi.MIX_ABSMEAN)
         one = torch.cuda.Stream()
@@ -522,8 +528,8 @@ def main():
             assert not two, "the C5 launches are expected to take the single-kernel form"
             kernel_label = "stft_db_kernel<Cfg4096B, AbsMean, ARGB out> (the workgroups colour their own columns)"
         else:
-            kname = jsg.stft_db_strided_kernel_name(plan, d_in[:bpd], hop, F, d_out[:bpd], **mixk)
-            kernel_label = f"stft_db_kernel<{kname}, {'one channel per column' if C == 1 else 'AbsMean'}, dB out{', strided' if bpd > 1 else ''}>"
+            kname = jsg.stft_db_strided_kernel_name(plan, d_in[:bpd], hop, F, d_out[:bpd], d_tail=(d_tail[:bpd] if use_tail else None), **mixk)
+            kernel_label = f"stft_db_kernel<{kname}, {'one channel per column' if C == 1 else 'AbsMean'}, dB out{', strided' if bpd > 1 else ''}{', tail plane' if use_tail else ''}>"
 
         def dispatch(stream_handle, b=0):
             if c["colour"] and strided:
@@ -531,9 +537,9 @@ def main():
             elif c["colour"]:
                 jsg.stft_image(plan, d_in[b], hop, F, d_lut, -50.0, 50.0, d_img[b][:, :F], None, plan_select=2, stream=stream_handle, **mixk)
             elif strided:
-                jsg.stft_db_strided(plan, d_in, hop, F, d_out, blocks_per_cu=args.blocks_per_cu, stream=stream_handle, **mixk)
+                jsg.stft_db_strided(plan, d_in, hop, F, d_out, d_tail=d_tail, blocks_per_cu=args.blocks_per_cu, stream=stream_handle, **mixk)
             else:
-                jsg.stft_db(plan, d_in[b], hop, F, d_out[b], blocks_per_cu=args.blocks_per_cu, stream=stream_handle, **mixk)
+                jsg.stft_db(plan, d_in[b], hop, F, d_out[b], d_tail=(d_tail[b] if use_tail else None), blocks_per_cu=args.blocks_per_cu, stream=stream_handle, **mixk)
 
         def run_step():
             h = one.cuda_stream
@@ -576,11 +582,11 @@ def main():
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(one):
             for b in range(nbuf):
-                jsg.stft_db(plan, d_in[b], hop, F, d_out[b], stream=one.cuda_stream, **mixk)
+                jsg.stft_db(plan, d_in[b], hop, F, d_out[b], d_tail=(d_tail[b] if use_tail else None), stream=one.cuda_stream, **mixk)
             torch.cuda.synchronize()
             with torch.cuda.graph(g, stream=one):
                 for b in range(nbuf):
-                    jsg.stft_db(plan, d_in[b], hop, F, d_out[b], stream=one.cuda_stream, **mixk)
+                    jsg.stft_db(plan, d_in[b], hop, F, d_out[b], d_tail=(d_tail[b] if use_tail else None), stream=one.cuda_stream, **mixk)
             g.replay(); g.replay()
             torch.cuda.synchronize()
             s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -590,6 +596,23 @@ def main():
             s1.record(one)
         torch.cuda.synchronize()
         single_us = s0.elapsed_time(s1) * 1e3 / (8 * nbuf)
+    reference_layout_us = None
+    if not args.dry_run and strided and use_tail and not args.no_single:
+        # ---- the same dispatches with the reference's column layout (bin n/2 inline, 128-byte-aligned columns of n/2+1 floats rounded up
+        #      to 32): what the tail plane buys, measured in this process on this box ----
+        d_ref = torch.empty((nbuf, F, ref_pitch), dtype=torch.float32, device="cuda")
+        with torch.cuda.stream(one):
+            for _ in range(3):
+                jsg.stft_db_strided(plan, d_in, hop, F, d_ref, blocks_per_cu=args.blocks_per_cu, stream=one.cuda_stream, **mixk)
+            r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            r0.record(one)
+            for _ in range(3 * dps):
+                jsg.stft_db_strided(plan, d_in, hop, F, d_ref, blocks_per_cu=args.blocks_per_cu, stream=one.cuda_stream, **mixk)
+            r1.record(one)
+        torch.cuda.synchronize()
+        reference_layout_us = r0.elapsed_time(r1) * 1e3 / (3 * dps)
+        ref_same = bool(torch.equal(d_ref[..., :n // 2], d_out) and torch.equal(d_ref[..., n // 2], d_tail[:, 0, :]))
+        del d_ref
     barrier(); sync()
     if dist is not None:
         t = torch.tensor([wall, dispatch_us or 0.0], dtype=torch.float64, device=red_dev)
@@ -622,12 +645,15 @@ def main():
                 d_out.fill_(-7.0)
                 dispatch(one.cuda_stream)
                 pin = 0 if n not in (2048, 4096) else (2 if "B," in kernel_label else 1)
-                tmp = torch.empty((F, pitch), dtype=torch.float32, device="cuda")
+                tmp = torch.empty((F, ref_pitch), dtype=torch.float32, device="cuda")      # single launches in the REFERENCE layout
                 differing = 0
                 for k in sorted({0, nbuf // 2, nbuf - 1}):
                     tmp.fill_(-7.0)
                     jsg.stft_db(plan, d_in[k], hop, F, tmp, plan_select=pin, stream=one.cuda_stream, **mixk)
-                    differing += int((tmp != d_out[k]).sum())
+                    if use_tail:
+                        differing += int((tmp[:, :n // 2] != d_out[k]).sum()) + int((tmp[:, n // 2] != d_tail[k, 0]).sum())
+                    else:
+                        differing += int((tmp != d_out[k]).sum())
                 parity["strided_columns_differing_from_single_launches"] = differing
         torch.cuda.synchronize()
 
@@ -643,6 +669,8 @@ def main():
                    "dispatches_per_step": dps, "batches_per_dispatch": bpd, "frames_per_batch": F * C, "columns_per_batch": F, "frames_per_dispatch": F * C * bpd,
                    "channels_per_gpu": C, "distinct_batches": nbuf, "rotation_bytes": None if args.dry_run else int(nbuf * per_batch),
                    "hip_streams_per_gpu": 1, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+                   "column_layout": None if args.dry_run else ("n/2 floats per column + dense plane of bin n/2 (jsg_stft_args.out_tail)" if use_tail else
+                                                               ("ARGB image rows" if c["colour"] else "reference: n/2+1 floats per column, pitch rounded up to 32 floats")),
                    "issue": (("jsg_stft_image_launch_strided" if c["colour"] else "jsg_stft_db_launch_strided") +
                              f": K = {bpd} independent {'images' if c['colour'] else f'{F}-frame batches'} per kernel dispatch, the dispatches of a step back to back "
                              "on ONE stream, issued by plain C calls (no hipGraph, no extra streams, no hardware-queue setting)") if strided else
@@ -684,6 +712,12 @@ def main():
             "second_roof": valu_roof(c, units_per_batch * bpd, dispatch_us, ((power or {}).get("path_sustained") or {}).get("sclk_MHz_median")),
             "commit": commit,
         }
+        if reference_layout_us:
+            out["roofline"]["reference_column_layout"] = {
+                "what": "the same strided dispatches writing the reference's column layout (bin n/2 inline: a 4-byte piece in one more 128-byte line per "
+                        "column) instead of columns of n/2 floats + a dense plane of bin n/2 (jsg_stft_args.out_tail); same values",
+                "avg_dispatch_us": reference_layout_us, "frac": algo / (reference_layout_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "units_per_s": units_per_batch * bpd / (reference_layout_us * 1e-6), "values_identical_to_the_timed_layout": ref_same}
         if single_us:
             out["roofline"]["one_batch_per_dispatch"] = {
                 "what": f"the same batches, ONE jsg_stft_db_launch per {F}-frame batch, in order on one stream (hipGraph replay of the rotation, HIP events)",

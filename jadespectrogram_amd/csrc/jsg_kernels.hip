@@ -171,6 +171,7 @@ struct jsg_plan {
     float2* d_tab = nullptr;
     size_t tab_elems = 0;
     float2* d_tab_b = nullptr;   // 2048 / 4096 points: lane tables of the second plan (Cfg2048B / Cfg4096B), behind d_tab in the same allocation
+    float2* d_tab_p = nullptr;   // 2048 points: lane tables of the pair plan (Cfg2048P), behind those
 };
 
 extern "C" {
@@ -189,7 +190,7 @@ int jsg_plan_create(jsg_plan** out, int n, const float* window, float power_scal
     *out = nullptr;
     if (!(power_scale > 0.f)) return jsg_fail(JSG_ERR_INVALID, "jsg_plan_create: power_scale must be > 0");
     std::vector<float2> t;
-    size_t tab_b_at = 0;
+    size_t tab_b_at = 0, tab_p_at = 0;
     const double amp = std::sqrt(double(power_scale));   // |FFT(a w x)|^2 = a^2 |FFT(w x)|^2
     switch (n) {
         case 512: fill_tables<Cfg512>(t, window, amp); break;
@@ -200,6 +201,10 @@ int jsg_plan_create(jsg_plan** out, int n, const float* window, float power_scal
             fill_tables<Cfg2048B>(tb, window, amp);
             t.resize((t.size() + 31) / 32 * 32, make_float2(0.f, 0.f));
             tab_b_at = t.size();
+            t.insert(t.end(), tb.begin(), tb.end());
+            fill_tables<Cfg2048P>(tb, window, amp);   // ... and the pair plan's
+            t.resize((t.size() + 31) / 32 * 32, make_float2(0.f, 0.f));
+            tab_p_at = t.size();
             t.insert(t.end(), tb.begin(), tb.end());
             break;
         }
@@ -236,7 +241,7 @@ int jsg_plan_create(jsg_plan** out, int n, const float* window, float power_scal
     switch (n) {
         case 512: err = ensure_attrs_Cfg512(); break;
         case 1024: err = ensure_attrs_Cfg1024(); if (err == hipSuccess) err = ensure_attrs_Cfg1024I(); break;
-        case 2048: err = ensure_attrs_Cfg2048(); if (err == hipSuccess) err = ensure_attrs_Cfg2048B(); break;
+        case 2048: err = ensure_attrs_Cfg2048(); if (err == hipSuccess) err = ensure_attrs_Cfg2048B(); if (err == hipSuccess) err = ensure_attrs_Cfg2048P(); break;
         case 4096: err = ensure_attrs_Cfg4096(); if (err == hipSuccess) err = ensure_attrs_Cfg4096B(); break;
         case 8192: err = ensure_attrs_Cfg8192(); break;
     }
@@ -248,6 +253,7 @@ int jsg_plan_create(jsg_plan** out, int n, const float* window, float power_scal
         return jsg_fail_hip(err, "jsg_plan_create");
     }
     if (tab_b_at) p->d_tab_b = p->d_tab + tab_b_at;
+    if (tab_p_at) p->d_tab_p = p->d_tab + tab_p_at;
     pool_prepare_for_device(p->device);
     *out = p;
     return JSG_OK;
@@ -281,12 +287,27 @@ struct IndexOut {   // fused display path: where and how the palette indices of 
 };
 }  // namespace
 
+// 2048 points: does this launch take the pair plan (Cfg2048P: a channel PAIR as one complex transform)?  Sum-type mixes (AbsMean, Sum)
+// over an EVEN number of channels, float columns (not the display launches), and -- like the "B" kernels, it runs one 8-wave workgroup
+// per CU, here of eight columns -- launches that fill their rounds.  plan_select = 3 pins it where it applies (else: as 0).
+constexpr bool kPairPlanByDefault = false;  // automatic selection: measured ahead of Cfg2048B where it applies
+static bool wants_plan_pair(int n, const jsg_stft_args* g, int n_cu, bool display, long long frames_of_launch = -1) {
+    if (n != 2048 || display) return false;
+    if (g->mix_mode != JSG_MIX_ABSMEAN && g->mix_mode != JSG_MIX_SUM) return false;
+    if (g->channels < 2 || (g->channels & 1)) return false;
+    if (g->plan_select == 3) return true;
+    if (g->plan_select != 0 || !kPairPlanByDefault) return false;
+    static const int forced2048 = dev_knob_int("JSG_2048_PLAN");   // variant builds only: 4 = pair plan, 2 / 3 = not
+    if (forced2048) return forced2048 == 4;
+    return b_plan_fills_its_rounds(frames_of_launch >= 0 ? frames_of_launch : g->n_frames, Cfg2048P::TPB, n_cu);
+}
+
 // 2048 / 4096 points: does this launch take the "B" kernel?  (nc: channels combined into one column)
 static bool wants_plan_b(int n, const jsg_stft_args* g, int nc, int n_cu, long long frames_of_launch = -1) {   // (-1: g->n_frames)
     if (n != 2048 && n != 4096) return false;
     static const int forced2048 = dev_knob_int("JSG_2048_PLAN");   // variant builds only (JSG_DEV_KNOBS): 2 = "B" | 3
     static const int forced4096 = dev_knob_int("JSG_4096_PLAN");
-    const int forced = g->plan_select == 1 ? 3 : g->plan_select == 2 ? 2 : (n == 2048 ? forced2048 : forced4096);
+    const int forced = g->plan_select == 1 ? 3 : g->plan_select == 2 ? 2 : (n == 2048 ? (forced2048 == 4 ? 0 : forced2048) : forced4096);
     const int tpb_b = n == 2048 ? Cfg2048B::TPB : Cfg4096B::TPB;
     return forced == 2 || (forced != 3 && nc >= (n == 2048 ? k2048B_min_channels : k4096B_min_channels) &&
                            b_plan_fills_its_rounds(frames_of_launch >= 0 ? frames_of_launch : g->n_frames, tpb_b, n_cu));
@@ -406,14 +427,17 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     // (the single-kernel display path exists for the one-wavefront-per-frame plans: at 4096 points that is "B")
     const long long rows = bs ? (long long)bs->n * (ka.per_channel ? g->channels : 1) : 1;
     // (a strided launch is judged by the frames of ALL its rows: the "B" kernels then fill their rounds)
-    const bool plan_b = (io && io->argb && plan->n == 4096) ||
-                        wants_plan_b(plan->n, g, ka.per_channel ? 1 : ka.c_end - ka.c_begin, n_cu, bs ? rows * g->n_frames : -1);
+    const bool plan_p = wants_plan_pair(plan->n, g, n_cu, io != nullptr, bs ? rows * g->n_frames : -1) && mixop == 0 && !ka.per_channel &&
+                        ((ka.c_end - ka.c_begin) & 1) == 0;
+    const bool plan_b = !plan_p && ((io && io->argb && plan->n == 4096) ||
+                        wants_plan_b(plan->n, g, ka.per_channel ? 1 : ka.c_end - ka.c_begin, n_cu, bs ? rows * g->n_frames : -1));
     if (plan_b) ka.tab = plan->d_tab_b;
+    if (plan_p) ka.tab = plan->d_tab_p;
     int tpb = 0;
     switch (plan->n) {
         case 512: tpb = Cfg512::TPB; break;
         case 1024: tpb = (io && io->argb) ? Cfg1024I::TPB : Cfg1024::TPB; break;   // (the display path's eight-column workgroups)
-        case 2048: tpb = plan_b ? Cfg2048B::TPB : Cfg2048::TPB; break;
+        case 2048: tpb = plan_p ? Cfg2048P::TPB : plan_b ? Cfg2048B::TPB : Cfg2048::TPB; break;
         case 4096: tpb = plan_b ? Cfg4096B::TPB : Cfg4096::TPB; break;
         case 8192: tpb = Cfg8192::TPB; break;
     }
@@ -446,7 +470,7 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     // workgroups per CU of the grid; the rest of the frames is looped over.  The "B" plans hold one workgroup per CU: a grid of
     // exactly that many keeps the tables and the prefetch pipeline alive across a workgroup's frames (16 384 mono 4096-point
     // frames: 65 vs 79 us with a grid of 8 per CU); the other plans do best with more workgroups than are resident.
-    const int bpc = g->blocks_per_cu > 0 ? g->blocks_per_cu : (blocks_per_cu_env > 0 ? blocks_per_cu_env : (plan_b ? 1 : 8));
+    const int bpc = g->blocks_per_cu > 0 ? g->blocks_per_cu : (blocks_per_cu_env > 0 ? blocks_per_cu_env : ((plan_b || plan_p) ? 1 : 8));
     long long max_blocks = (long long)n_cu * bpc / ny;     // resident workgroups; the rest is looped over
     if (max_blocks < 64) max_blocks = 64;
     static const int max_blocks_env = dev_knob_int("JSG_STFT_MAX_BLOCKS");
@@ -463,7 +487,7 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
         switch (plan->n) {
             case 512: err = launch_strided_Cfg512(ka, mixop, grid, s); break;
             case 1024: err = launch_strided_Cfg1024(ka, mixop, grid, s); break;
-            case 2048: err = plan_b ? launch_strided_Cfg2048B(ka, mixop, grid, s) : launch_strided_Cfg2048(ka, mixop, grid, s); break;
+            case 2048: err = plan_p ? launch_strided_Cfg2048P(ka, mixop, grid, s) : plan_b ? launch_strided_Cfg2048B(ka, mixop, grid, s) : launch_strided_Cfg2048(ka, mixop, grid, s); break;
             case 4096: err = plan_b ? launch_strided_Cfg4096B(ka, mixop, grid, s) : launch_strided_Cfg4096(ka, mixop, grid, s); break;
             case 8192: err = launch_strided_Cfg8192(ka, mixop, grid, s); break;
         }
@@ -473,7 +497,7 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     switch (plan->n) {
         case 512: err = launch_Cfg512(ka, mixop, grid, s); break;
         case 1024: err = (io && io->argb) ? launch_Cfg1024I(ka, mixop, grid, s) : launch_Cfg1024(ka, mixop, grid, s); break;
-        case 2048: err = plan_b ? launch_Cfg2048B(ka, mixop, grid, s) : launch_Cfg2048(ka, mixop, grid, s); break;
+        case 2048: err = plan_p ? launch_Cfg2048P(ka, mixop, grid, s) : plan_b ? launch_Cfg2048B(ka, mixop, grid, s) : launch_Cfg2048(ka, mixop, grid, s); break;
         case 4096: err = plan_b ? launch_Cfg4096B(ka, mixop, grid, s) : launch_Cfg4096(ka, mixop, grid, s); break;
         case 8192: err = launch_Cfg8192(ka, mixop, grid, s); break;
     }
@@ -493,8 +517,9 @@ int jsg_stft_kernel_name(const jsg_plan* plan, const jsg_stft_args* g, char* out
     if (hipGetDevice(&dev) != hipSuccess) return jsg_fail(JSG_ERR_NO_DEVICE, "jsg_stft_kernel_name: no device");
     int nc = g->channels;
     if (g->mix_mode == JSG_MIX_LEFT || g->mix_mode == JSG_MIX_RIGHT || g->mix_mode == JSG_MIX_PER_CHANNEL) nc = 1;
-    const bool b = wants_plan_b(plan->n, g, nc, cu_count_of_device(dev));
-    std::snprintf(out, size_t(out_len), "Cfg%d%s", plan->n, b ? "B" : "");
+    const bool pp = wants_plan_pair(plan->n, g, cu_count_of_device(dev), false);
+    const bool b = !pp && wants_plan_b(plan->n, g, nc, cu_count_of_device(dev));
+    std::snprintf(out, size_t(out_len), "Cfg%d%s", plan->n, pp ? "P" : b ? "B" : "");
     return JSG_OK;
 }
 
@@ -675,8 +700,9 @@ int jsg_stft_db_strided_kernel_name(const jsg_plan* plan, const jsg_stft_args* g
     int nc = g->channels;
     if (g->mix_mode == JSG_MIX_LEFT || g->mix_mode == JSG_MIX_RIGHT || g->mix_mode == JSG_MIX_PER_CHANNEL) nc = 1;
     const long long rows = (long long)n_batches * (g->mix_mode == JSG_MIX_PER_CHANNEL ? g->channels : 1);
-    const bool b = wants_plan_b(plan->n, g, nc, n_cu, rows * g->n_frames);
-    std::snprintf(out, size_t(out_len), "Cfg%d%s", plan->n, b ? "B" : "");
+    const bool pp = wants_plan_pair(plan->n, g, n_cu, false, rows * g->n_frames);
+    const bool b = !pp && wants_plan_b(plan->n, g, nc, n_cu, rows * g->n_frames);
+    std::snprintf(out, size_t(out_len), "Cfg%d%s", plan->n, pp ? "P" : b ? "B" : "");
     return JSG_OK;
 }
 

@@ -1,4 +1,5 @@
 // Translation unit B of the STFT kernels: the two 4096-point plans (default machine scheduler: see jsg_stft_a.hip).
+#define JSG_TWIDDLE_CONST_VGPR 1   // see mul_w_q1
 #include "jsg_stft_kernel.h"
 
 namespace jsg {

@@ -136,7 +136,14 @@ __device__ __forceinline__ cf mul_w_q1(cf v) {
         const cf t = v * c;
         const cf sv = {sn, sn};
         cf r;
+        // The sine as a SCALAR operand (unit A: the radix-32 plans hold seven of these constants as register pairs otherwise -- Cfg2048B 250
+        // -> 238 VGPRs, the pair plan 256 + a spill -> 244); unit B keeps them in vector registers (JSG_TWIDDLE_CONST_VGPR: with scalar
+        // operands the default scheduler of the 4096-point kernels pads 20 more s_nop per FFT round).  Same instruction, same bits.
+#ifdef JSG_TWIDDLE_CONST_VGPR
         asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(v), "v"(sv), "v"(t));
+#else
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(v), "s"(sv), "v"(t));
+#endif
         return r;
     }
 }
@@ -208,6 +215,39 @@ __device__ __forceinline__ void dft_win(cf (&x)[R], const cf (&w)[R / 2]) {
     }
 }
 
+// Pair plan (Cfg::PAIR): the samples are complex (z = x_c + i x_(c+1)) and the window is real, one float per sample, held as PAIRS of
+// consecutive values (w[m], w[m+1]) in one aligned register pair: the multiply broadcasts one of the two floats through the packed
+// instruction's operand selects (written out: the compiler derives the broadcast form for some uses and copies the float into a fresh
+// register pair for others -- 2 x v_mov each, 30 per round in the ISA of the first version).
+template <int HI>
+__device__ __forceinline__ cf mul_bc(cf v, cf wp) {   // v * wp[HI] (both components)
+    cf r;
+    if constexpr (HI) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(v), "v"(wp));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(v), "v"(wp));
+    return r;
+}
+template <int HI, bool NEG>
+__device__ __forceinline__ cf fma_bc(cf v, cf wp, cf c) {   // v * wp[HI] + c   (NEG: - c)
+    cf r;
+    if constexpr (HI && NEG) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(wp), "v"(c));
+    else if constexpr (HI) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(v), "v"(wp), "v"(c));
+    else if constexpr (NEG) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(wp), "v"(c));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(v), "v"(wp), "v"(c));
+    return r;
+}
+// The first butterfly layer of the pair plan's stage 1 with the window folded in, as DifLayerWin: hi = z[J + R/2] w[J + R/2] (one packed
+// multiply), a = fma(z[J], w[J], hi), d = fma(z[J], w[J], -hi), b = W_R^J d.  wp[i] = (w[2 i], w[2 i + 1]).
+template <int R, int J>
+struct PairFirstLayer {
+    static __device__ __forceinline__ void run(const cf (&z)[R], const cf (&wp)[R / 2], cf (&a)[R / 2], cf (&b)[R / 2]) {
+        const cf hi = mul_bc<(J + R / 2) % 2>(z[J + R / 2], wp[(J + R / 2) / 2]);
+        a[J] = fma_bc<J % 2, false>(z[J], wp[J / 2], hi);
+        const cf d = fma_bc<J % 2, true>(z[J], wp[J / 2], hi);
+        b[J] = mul_w_q1<J % (R / 4), R>(d);
+        if constexpr (J + 1 < R / 2) PairFirstLayer<R, J + 1>::run(z, wp, a, b);
+    }
+};
+
 // Lanes of one wavefront run in lock-step, so a wave-private LDS exchange needs no s_barrier; what it does need is
 // that the COMPILER keeps the stores ahead of the loads that other lanes of the same wave perform.
 __device__ __forceinline__ void wave_sync() {
@@ -231,9 +271,15 @@ __device__ __forceinline__ cf to_cf(const f2u& v) { return cf{v.x, v.y}; }
 //   interleaved frames per wavefront gave bit-identical results but were slower (tried and measured); the loops over F stay.
 // (Round 4: the development ablation / stamp modes that used to live in this kernel -- ABL, JSG_X_* switches, in-kernel time stamps --
 //   are gone from the product source; they are in the history, rounds 2-3, with the measurements they produced in DESIGN.md section 6.)
+// PAIR (round 5): the plan transforms a PAIR of channels as ONE complex sequence z = x1 + i x2 of N points (sum-type mixes over an even
+//   channel count): |X1[k]|^2 + |X2[k]|^2 = (|Z[k]|^2 + |Z[N-k]|^2) / 2, so no real-split post pass and no mirror exchange per channel
+//   frame -- one fold per COLUMN instead.  The N-point transform is split by decimation in time: the two half-waves of a wavefront (L = 32)
+//   transform the even and the odd samples (E, O: two N/2-point FFTs with the two-stage engine of Cfg2048B), a v_permlane32_swap brings
+//   E[k] and O[k] into one lane, and Z[k] = E[k] + W_N^k O[k], Z[k + N/2] = E[k] - W_N^k O[k].  See "pair plan" in the kernel.
 template <int N_, int R1_, int R2_, int R3_, int L_, int S1_, int AX_, int AY_, int AZ_, int WPB_, int TLOC_, int WPS_,
-          int FPW_ = 1, int RESERVED_ = 0, int TWF_ = 0>
+          int FPW_ = 1, int RESERVED_ = 0, int TWF_ = 0, int PAIR_ = 0>
 struct Cfg {
+    static constexpr bool PAIR = PAIR_ != 0;
     // TWF: factorised twiddle tables (for plans whose full lane tables do not fit beside the exchange buffers).  The stage-2
     // twiddle W_M^(n3 (k1 + R1 k2)) is read as B[n3][k2] = W_(M/R1)^(n3 k2) (one row per n3, shared by the lanes) times the
     // lane's constant A[v] = W_M^(n3 k1); the post-pass twiddle -i W_N^(ll + L rho) as the lane's constant C = -i W_N^ll times
@@ -249,7 +295,8 @@ struct Cfg {
     static constexpr int TL = L;                     // entries per lane-table row (L = 32: both half-waves read the same entries)
     static constexpr bool TWO_STAGE = R3_ == 1;      // R1 * R2 = M: one exchange, the second radix stage leaves bin ll + L*k2 in register k2
     static constexpr int WPB = WPB_;                 // wavefronts per workgroup
-    static constexpr int TPB = WPB * 64 / L * FPW;   // frames per workgroup per iteration
+    static constexpr int SLOTS = WPB * 64 / L * FPW; // exchange regions (sub-transforms in flight) per workgroup
+    static constexpr int TPB = PAIR ? WPB : SLOTS;   // frames (columns) per workgroup per iteration; PAIR: one column per wavefront
     static constexpr int TLOC = TLOC_;
     static constexpr int WPS = WPS_;                 // waves per SIMD the register allocator is asked to allow
     // Lane tables (float2 elements): window pairs [P][TL]; stage-1 twiddles W_{R1 R2}^{n2 k1}, which depend on the lane
@@ -271,7 +318,7 @@ struct Cfg {
     static constexpr int e2max = TWO_STAGE ? 0 : (R1 - 1) * AX + (R2 - 1) * AY + (R3 - 1) * AZ + 1;
     static constexpr int raw = e1max > e2max ? (e1max > M + 1 ? e1max : M + 1) : (e2max > M + 1 ? e2max : M + 1);
     static constexpr int LDS_ELEMS = (raw + 1) & ~1;  // float2 elements per frame slot, 16-byte multiple
-    static constexpr int LDS_BYTES = LDS_ELEMS * TPB * 8;                          // dynamic: exchange buffers
+    static constexpr int LDS_BYTES = LDS_ELEMS * SLOTS * 8;                        // dynamic: exchange buffers
     static constexpr int LDS_TOTAL = LDS_BYTES + (TLOC == 1 ? TAB_ELEMS : 2) * 8;  // + static: lane tables
     static_assert(R1 * R2 * R3 == M, "radices");
     static_assert(P % R1 == 0 && P % R2 == 0 && P % R3 == 0, "each lane owns whole butterflies");
@@ -280,6 +327,11 @@ struct Cfg {
     static_assert(TLOC == 0 || TLOC == 1, "lane tables in registers: removed (DESIGN.md, tried and measured)");
     static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget of one CU");
     static_assert(!TWF || ((N_ / L_ == 64 || N_ / L_ == 32) && L_ % R3_ == 0 && !TWO_STAGE && TLOC_ == 1), "factorised tables: 4096-point plans");
+    // PAIR: the window table holds P x 64 FLOATS (w[64 m + 2 ll + h], four values of a lane side by side: [P/4][64][4]) in the P*TL float2
+    // elements of TAB_WIN, and TAB_POST holds the last stage's twiddles W_N^(lane + 64 j), j < P/4, as [P/4][64] pairs of j (tab_idx with 64
+    // entries per row) -- the same element counts as the tables of Cfg2048B, so the LDS budget is that plan's
+    static_assert(!PAIR || (TWO_STAGE && L_ == 32 && FPW_ == 1 && TLOC_ == 1 && !TWF && P % 4 == 0 && (P / 2) * TL == (P / 4) * 64), "pair plan: two-stage, 32 lanes per half");
+    static constexpr int pair_tw_idx(int j, int lane) { return ((j / 2) * 64 + lane) * 2 + j % 2; }
 };
 
 using Cfg512 = Cfg<512, 8, 8, 4, 32, 36, 4, 33, 1, 8, 1, 2>;   // (a 80-VGPR budget = 3 workgroups per CU measured no faster)
@@ -307,6 +359,13 @@ using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 1, 3, 1, 0, 1>;   // (
 // for anything smaller the 4-frame workgroups of the three-stage plan use more CUs (tools/abbench --cfg x2048 / mid).
 // The launcher picks by channel count and by how well the launch fills its rounds (stft_launch_impl).
 using Cfg2048B = Cfg<2048, 32, 32, 1, 32, 34, 0, 0, 0, 8, 1, 1>;
+// The pair plan (round 5): the same two radix-32 stages and the same single exchange per 1024-point sub-transform, but a
+// wavefront transforms the channel pair (c, c + 1) of ONE column as z = x_c + i x_(c+1): half-wave 0 the even samples, half-wave 1 the odd
+// ones, one radix-2 stage across the half-waves (v_permlane32_swap + one twiddle), |Z|^2 accumulated over the pairs of the column in
+// registers (bins 0 .. 2047 of the complex spectrum), and ONE fold per column: out[k] = (acc[k] + acc[2048 - k]) / 2 / channels.
+// Against Cfg2048B per two channel FFTs: no paired post pass (2 x 72 vector instructions) and no mirror exchange (2 x 33 LDS instructions),
+// instead 32 swaps + 32 twiddle + 32 butterfly + 32 power instructions and, per column, a 16-value mirror exchange.
+using Cfg2048P = Cfg<2048, 32, 32, 1, 32, 34, 0, 0, 0, 8, 1, 1, 1, 0, 0, 1>;
 constexpr int k2048B_min_channels = 2;   // channels mixed into one column from which the two-stage plan is the faster one (round 3, ILP-first
                                          // scheduler, 32 768 FFTs per launch: stereo 42.9-52.8 vs 48.1-55.9 us, 4 ch 41.3-49.1 vs 45.1-52.0, 8 ch
                                          // 39.6-46.5 vs 44.8-50.6; mono level: 51.2-62.7 vs 52.1-61.2)
@@ -505,8 +564,10 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     // L <= 64 plan owns the SUB * F consecutive slots from slot0 on: slot0 + sub * F + f
     const int ll = L <= 64 ? lane % L : (wave % C::WPF) * 64 + lane;
     const int sub = L <= 64 ? lane / L : 0;
-    const int slot0 = L <= 64 ? wave * C::SUB * F : wave / C::WPF;   // wave-uniform part of the slot
-    cf* const lds0 = reinterpret_cast<cf*>(smem_raw) + (slot0 + sub * F) * C::LDS_ELEMS;   // frame f: lds0 + f * LDS_ELEMS
+    // (pair plan: a wavefront owns ONE column -- task slot = wave -- and both of its half-waves' exchange regions, 2 wave + sub)
+    const int slot0 = C::PAIR ? wave : (L <= 64 ? wave * C::SUB * F : wave / C::WPF);   // wave-uniform part of the slot
+    const int tsub = C::PAIR ? 0 : sub;                                                   // the lane's frame among the wave's tasks
+    cf* const lds0 = reinterpret_cast<cf*>(smem_raw) + (C::PAIR ? wave * 2 + sub : slot0 + sub * F) * C::LDS_ELEMS;   // frame f: lds0 + f * LDS_ELEMS
     const int tl = ll;                                            // index into a lane-table row (TL = L entries)
 
     // XCD-aware block remap (bijective): blocks b, b+8, b+16.. share an XCD (and its L2); neighbouring workgroups are given to the
@@ -539,9 +600,11 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     const int c0 = a.per_channel ? (BAT ? 0 : (int)blockIdx.y) : a.c_begin;
     const int c1 = a.per_channel ? (BAT ? 1 : (int)blockIdx.y + 1) : a.c_end;
     constexpr bool ONE = MIXOP == 3;
-    const int nc = ONE ? 1 : c1 - c0;
+    // (pair plan: one FFT round transforms the channel PAIR c, c + 1; the launcher selects it for an even channel count only)
+    const int nc = ONE ? 1 : (C::PAIR ? (c1 - c0) / 2 : c1 - c0);   // FFT rounds per column
+    constexpr int CSTEP = C::PAIR ? 2 : 1;                            // channels per round
     __builtin_assume(a.iters >= 1 && nc >= 1);   // (the launcher guarantees it) keeps the first frame's loads unconditional
-    const int n_fft = a.iters * nc;   // FFT rounds this wave performs (F frames each), s = it*nc + (c - c0)
+    const int n_fft = a.iters * nc;   // FFT rounds this wave performs (F frames each), s = it*nc + (c - c0) / CSTEP
     // task (= frame of the launch) of frame f of this lane in iteration `it`; tasks past the end are given the last frame
     // again: they hold the same bits as that frame's own lanes and store them to the same column, so nothing is masked
     // OUTK == 2: group (= workgroup iteration) `it` of this workgroup -> image and first column inside that image (all scalar).  An
@@ -574,13 +637,13 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         if constexpr (OUTK == 2 || BAT) {
             unsigned image, col0;
             group_of(it, image, col0);
-            t = col0 + slot0 + sub * F + f;
-        } else t = task0 + it * task_stride + sub * F + f;
+            t = col0 + slot0 + tsub * F + f;
+        } else t = task0 + it * task_stride + tsub * F + f;
         return t < a.n_frames ? t : a.n_frames - 1;
     };
     auto frame_src = [&](int s, int f) -> const f2u* {
         const unsigned it = (nc == 1) ? (unsigned)s : (unsigned)s / (unsigned)nc;
-        const int c = c0 + (s - (int)it * nc);
+        const int c = c0 + CSTEP * (s - (int)it * nc);
         const unsigned j = a.first_frame + task_of(it, f);
         long long start;
         if (a.regular) {
@@ -601,7 +664,30 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
             row_of(row, in_off, out_off);
             start += in_off;
         }
+        if constexpr (C::PAIR)   // the lane's samples of BOTH channels: x_c[start + 64 m + 2 ll + h] (see frame_load)
+            return reinterpret_cast<const f2u*>(a.in + (long long)c * a.in_pitch + start + (2 * ll + sub));
+        else
         return reinterpret_cast<const f2u*>(a.in + (long long)c * a.in_pitch + start) + ll;
+    };
+    // the P loads of one frame (pair plan: 2 P dword loads -- the sample of channel c into .x, of channel c + 1 into .y: the lane holds
+    // z[n] = x_c[n] + i x_(c+1)[n] for n = 2 (ll + 32 m) + h, i.e. half-wave h the samples of parity h; a wave instruction reads 64
+    // consecutive floats)
+    // part: 0 = all of them, 1 / 2 = the first / second half of the pair plan's loads (see the prefetch in process())
+    auto frame_load = [&](f2u (&dst)[P], const f2u* src, int part = 0) {
+        if constexpr (C::PAIR) {
+            const float* p1 = reinterpret_cast<const float*>(src);
+            const float* p2 = p1 + a.in_pitch;
+#pragma unroll
+            for (int m = 0; m < P; ++m) {
+                if (part == 1 && m >= P / 2) continue;
+                if (part == 2 && m < P / 2) continue;
+                dst[m].x = p1[64 * m];
+                dst[m].y = p2[64 * m];
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < P; ++m) dst[m] = src[L * m];
+        }
     };
     // ---- lane tables first: two 16-byte LDS-DMA pieces per thread bring the tables from L2 straight into LDS (wave-uniform
     //      base + lane * 16 bytes, no VGPR round trip).  They are issued AHEAD of the frame loads: every wave's FFT start is
@@ -623,11 +709,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     f2u raw[F][P];
     {
 #pragma unroll
-        for (int f = 0; f < F; ++f) {
-            const f2u* src = frame_src(0, f);
-#pragma unroll
-            for (int m = 0; m < P; ++m) raw[f][m] = src[L * m];
-        }
+        for (int f = 0; f < F; ++f) frame_load(raw[f], frame_src(0, f));
         __builtin_amdgcn_sched_barrier(0);
     }
     const cf* tBase;   // start of the tables (LDS copy, or global memory for TLOC == 0)
@@ -635,7 +717,9 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         // the table pieces are older than the F * P frame loads of this wave: a counted vmcnt retires them and leaves the
         // frames in flight (an LDS-DMA is a pending LDS write on the VM counter; __syncthreads() would drain everything)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (compiler only) the frame loads stay above the counted wait
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(F * P) : "memory");
+        // (pair plan: 2 P = 64 frame loads, one more than the 6-bit counter can name: the wait then also retires the oldest frame load)
+        constexpr int NFL = (C::PAIR ? 2 : 1) * F * P;
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NFL > 63 ? 63 : NFL) : "memory");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         tBase = s_tab;
     } else {
@@ -688,6 +772,12 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         e2w[0] = e2r[0] = 0;
     }
 
+    // pair plan: (sum of Re^2, sum of Im^2) over the channel pairs of the column, of Z[k] (accU) and Z[k + M] (accV), k = lane + 64 j
+    cf accU[C::PAIR ? P / 2 : 1], accV[C::PAIR ? P / 2 : 1];
+    if constexpr (C::PAIR) {
+#pragma unroll
+        for (int j = 0; j < P / 2; ++j) accU[j] = accV[j] = cf{0.f, 0.f};
+    }
     cf acc[F][P / 2];   // .x: bin k = ll + L rho of the lower half, .y: its mirror M - k (filled as pairs by the post pass)
     float accNy[F];
     constexpr float init = (MIXOP == 2) ? 1000000.0f : 0.0f;   // reference Spectrogram.cpp:69,78,86
@@ -711,6 +801,11 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         // ---- window multiply: register m = u + U1 n1 is input n1 of stage-1 butterfly u.  The upper inputs (n1 >= R1 / 2) are multiplied
         //      here; the lower ones stay raw and keep their window values, their products are fused into the butterfly (dft_win) ----
         cf wlo[P / 2];   // window values of the lower inputs, index (m % U1) + U1 * n1 == m for m < P / 2
+        if constexpr (C::PAIR) {
+            // one real window value per complex sample z = x_c + i x_(c+1): four values of this lane per 16-byte read ([P/4][64][4] floats)
+            static_assert(F == 1, "pair plan");
+            // (the values are used as pairs (w[m], w[m + 1]): see PairFirstLayer, which does the multiplies)
+        } else {
 #pragma unroll
         for (int m = 0; m < P; m += 2) {
             cf w0, w1;
@@ -728,12 +823,37 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
             }
             if (m < P / 2) { wlo[m] = w0; wlo[m + 1] = w1; }
         }
+        }
+        // pair plan: the first butterfly layer of stage 1 runs HERE, ahead of the prefetch: it consumes every raw value, so the loads below
+        // can land in the registers they leave.  (Left to the scheduler, the raw lower inputs -- which the other plans' register allocation
+        // keeps through the prefetch for free -- were copied first: 38 v_mov per round in the ISA.)
+        cf pa[C::PAIR ? R1 / 2 : 1], pb[C::PAIR ? R1 / 2 : 1];
+        if constexpr (C::PAIR) {
+            static_assert(!C::PAIR || U1 == 1, "pair plan: one radix-R1 butterfly per lane");
+            const float* wtab = reinterpret_cast<const float*>(tBase + C::TAB_WIN) + lane * 4;
+            cf wp[P / 2], zr[P];
+#pragma unroll
+            for (int m = 0; m < P; m += 4) {
+                const v4f w4 = *reinterpret_cast<const v4f*>(wtab + (m / 4) * 256);
+                wp[m / 2] = cf{w4.x, w4.y};
+                wp[m / 2 + 1] = cf{w4.z, w4.w};
+            }
+#pragma unroll
+            for (int m = 0; m < P; ++m) zr[m] = to_cf(raw[0][m]);
+            PairFirstLayer<R1, 0>::run(zr, wp, pa, pb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // (pair plan: 2 P = 64 dword loads per round, and a wave can have 63 vector-memory instructions outstanding -- the 64th would hold
+        // the wave's issue until the first has returned, a full memory round trip per FFT round.  The first half goes out here, the second
+        // behind stage 1, when part of the first has arrived.)
+        const f2u* next_src = nullptr;
         if (!LAST) {   // the next round's frames travel while this one is transformed
+            if constexpr (C::PAIR) {
+                next_src = frame_src(s + 1, 0);
+                frame_load(raw[0], next_src, 1);
+            } else {
 #pragma unroll
-            for (int f = 0; f < F; ++f) {
-                const f2u* src = frame_src(s + 1, f);
-#pragma unroll
-                for (int m = 0; m < P; ++m) raw[f][m] = src[L * m];
+            for (int f = 0; f < F; ++f) frame_load(raw[f], frame_src(s + 1, f));
             }
         }
         JSG_MARK(1);
@@ -746,10 +866,20 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
             for (int f = 0; f < F; ++f) {
 #pragma unroll
                 for (int n1 = 0; n1 < R1; ++n1) t[f][n1] = x[f][u + U1 * n1];
+                if constexpr (C::PAIR) {   // the rest of dft_win<R1> (its first layer ran above)
+                    dft<R1 / 2, false>(pa);
+                    dft<R1 / 2, true>(pb);
+#pragma unroll
+                    for (int q = 0; q < R1 / 2; ++q) {
+                        t[f][2 * q] = pa[q];
+                        t[f][2 * q + 1] = pb[q];
+                    }
+                } else {
                 cf wl[R1 / 2];
 #pragma unroll
                 for (int n1 = 0; n1 < R1 / 2; ++n1) wl[n1] = wlo[u + U1 * n1];
                 dft_win<R1>(t[f], wl);
+                }
                 lds0[f * C::LDS_ELEMS + ll + L * u] = t[f][0];
             }
 #pragma unroll
@@ -763,6 +893,13 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
             }
         }
         JSG_MARK(3);
+        if constexpr (C::PAIR) {
+            if (!LAST) {
+                __builtin_amdgcn_sched_barrier(0);
+                frame_load(raw[0], next_src, 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         frame_sync();
 #pragma unroll
         for (int f = 0; f < F; ++f)
@@ -858,7 +995,32 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         } else {
             frame_sync();   // the post pass reuses the exchange buffer: keep its stores behind the exchange-1 loads
         }
-        {
+        if constexpr (C::PAIR) {
+            // ---- pair plan, last stage (radix 2 across the half-waves).  Register k2 of half-wave h holds Y_h[ll + 32 k2], the 1024-point
+            // transforms of the even (h = 0: E) and odd (h = 1: O) samples of z.  v_permlane32_swap trades the upper half of register 2 j
+            // against the lower half of register 2 j + 1: afterwards register 2 j holds E[k] and register 2 j + 1 holds O[k], k = lane + 64 j,
+            // over all 64 lanes.  Z[k] = E[k] + W_N^k O[k], Z[k + M] = E[k] - W_N^k O[k]; the table holds W_N^k for j < P/4 and
+            // W_N^(k + M/2) = -i W_N^k serves the rest (add_mi / sub_mi: the -i costs nothing).  The powers are accumulated as
+            // (sum Re^2, sum Im^2): one packed fma per spectrum value and channel pair.
+            constexpr int Q4 = P / 4;
+#pragma unroll
+            for (int jp = 0; jp < Q4; jp += 2) {
+                const v4f q4 = *reinterpret_cast<const v4f*>(tBase + C::TAB_POST + C::pair_tw_idx(jp, lane));
+                const cf tw0 = {q4.x, q4.y}, tw1 = {q4.z, q4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int j = jp + (i & 1) + (i >> 1) * Q4;
+                    const auto re = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[0][2 * j].x), __float_as_uint(x[0][2 * j + 1].x), false, false);
+                    const auto im = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[0][2 * j].y), __float_as_uint(x[0][2 * j + 1].y), false, false);
+                    const cf E = {__uint_as_float(re[0]), __uint_as_float(im[0])};
+                    const cf O = cmul(cf{__uint_as_float(re[1]), __uint_as_float(im[1])}, (i & 1) ? tw1 : tw0);
+                    const cf Z = (i >> 1) ? add_mi(E, O) : E + O;
+                    const cf Zm = (i >> 1) ? sub_mi(E, O) : E - O;
+                    accU[j] = __builtin_elementwise_fma(Z, Z, accU[j]);
+                    accV[j] = __builtin_elementwise_fma(Zm, Zm, accV[j]);
+                }
+            }
+        } else {
             JSG_MARK(7);
             // ---- paired real-split post pass.  Bin k = ll + L*rho (rho = w + U3*k3).  A lane owns the pairs of its
             // lower registers rho < P/2: (k, M-k); Z[M-k] is the upper register P-1-rho of lane L-ll (lane 0: its own
@@ -924,6 +1086,65 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
 
         // ---- last channel of this column: mix epilogue + dB + ring store ----
         const unsigned it = (nc == 1) ? (unsigned)s : (unsigned)s / (unsigned)nc;
+        if constexpr (C::PAIR) {
+            // ---- pair plan: ONE fold per column.  acc[k] = sum over the pairs of |Z[k]|^2 for the N bins of the complex spectrum: U[j] =
+            // acc[k], V[j] = acc[k + M], k = lane + 64 j.  The column is out[k] = (acc[k] + acc[N - k]) / 2 = (U[k] + V[M - k]) / 2 for
+            // 0 < k < M, out[0] = U[0], out[M] = V[0] (sum over the channels; AbsMean: / channels).  V[M - k] lives in lane 64 - lane,
+            // register P/2 - 1 - j (lane 0: its own register P/2 - j): one mirror exchange of P/2 floats per lane through the wave's
+            // exchange region, per COLUMN (the paired post pass of the other plans exchanges P/2 complex values per channel frame).
+            static_assert(!C::PAIR || (MIXOP == 0 && OUTK == 0), "pair plan: sum-type mixes, float columns");
+            if (s - (int)it * nc == nc - 1) {
+                constexpr int J = P / 2;
+                unsigned col = a.ring_pos + task_of(it, 0);
+                if (col >= (unsigned)a.ring_w) col -= a.ring_w;
+                float* const ex = reinterpret_cast<float*>(reinterpret_cast<cf*>(smem_raw) + wave * 2 * C::LDS_ELEMS);   // wave-private
+                float U[J], V[J];
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    U[j] = accU[j].x + accU[j].y;
+                    V[j] = accV[j].x + accV[j].y;
+                    accU[j] = accV[j] = cf{0.f, 0.f};
+                }
+#pragma unroll
+                for (int j = 0; j < J; ++j) ex[lane + 64 * j] = V[j];
+                if (lane == 0) ex[M] = U[0];                 // "V[M]" := U[0]: out[0] = (U[0] + U[0]) / 2 exactly
+                wave_sync();
+                float o[J];
+#pragma unroll
+                for (int j = 0; j < J; ++j) o[j] = U[j] + ex[M - (lane + 64 * j)];
+                wave_sync();                                 // the next round's exchange stores stay behind these loads
+                float oM = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(V[0])));   // bin M = N/2 (uniform: unmasked store below)
+                oM = oM + oM;
+                if (a.exact_div) {   // (. / 2) / channels: the halving is exact, the division IEEE (Spectrogram.cpp:74)
+#pragma unroll
+                    for (int j = 0; j < J; ++j) o[j] = (o[j] * 0.5f) / a.divisor;
+                    oM = (oM * 0.5f) / a.divisor;
+                } else {             // power-of-two channel count (or the plain sum): 1/2 and 1/channels as one exact scaling
+                    const float hs = 0.5f * a.scale;
+#pragma unroll
+                    for (int j = 0; j < J; ++j) o[j] *= hs;
+                    oM *= hs;
+                }
+                if (!a.linear) {
+#pragma unroll
+                    for (int j = 0; j < J; ++j) o[j] = XLOG ? jsg_exact_db(o[j]) : to_db(o[j]);
+                    oM = XLOG ? jsg_exact_db(oM) : to_db(oM);
+                }
+                long long cofs = 0ll;
+                unsigned trow = 0u;
+                if constexpr (BAT) {
+                    unsigned col0_;
+                    long long in_off;
+                    group_of(it, trow, col0_);
+                    row_of(trow, in_off, cofs);
+                }
+                float* dst = a.out + (long long)col * a.out_pitch + cofs;
+#pragma unroll
+                for (int j = 0; j < J; ++j) __builtin_nontemporal_store(o[j], &dst[lane + 64 * j]);   // 256 contiguous bytes per instruction
+                if (a.tail) a.tail[(long long)trow * a.ring_w + col] = oM;   // (plain store: see the tail plane of the other plans)
+                else __builtin_nontemporal_store(oM, &dst[M]);
+            }
+        } else
         if (ONE || s - (int)it * nc == nc - 1) {
 #pragma unroll
             for (int f = 0; f < F; ++f) {
@@ -1136,6 +1357,20 @@ void fill_tables(std::vector<float2>& t, const float* window, double amp) {
                 const double ang = -two_pi * double((long long)n3 * k2 % (M / R1)) / double(M / R1);
                 t[C::TAB_TW2 + n3 * C::TSB + k2] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
             }
+    if constexpr (C::PAIR) {
+        // window: P x 64 floats, value m of wavefront lane (ll, h) = w[64 m + 2 ll + h] * amp at [m / 4][lane][m % 4] (no 1/2: there is no
+        // paired post pass); last stage: W_N^(lane + 64 j), j < P/4, pairs of j side by side (Cfg::pair_tw_idx)
+        float* wf = reinterpret_cast<float*>(t.data() + C::TAB_WIN);
+        for (int lane = 0; lane < 64; ++lane) {
+            const int q = 2 * (lane % L) + lane / L;
+            for (int m = 0; m < P; ++m) wf[(m / 4) * 256 + lane * 4 + m % 4] = float(double(window[64 * m + q]) * amp);
+            for (int j = 0; j < P / 4; ++j) {
+                const double ang = -two_pi * double(lane + 64 * j) / double(N);
+                t[C::TAB_POST + C::pair_tw_idx(j, lane)] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
+            }
+        }
+        return;
+    }
     for (int e = 0; e < TL; ++e) {   // entry e of a table row belongs to lane-in-frame ll (L = 32: both half-waves)
         const int ll = e % L;
         for (int m = 0; m < P; ++m) {   // window pairs: samples 2n, 2n+1 with n = ll + L m
@@ -1196,6 +1431,11 @@ constexpr bool image_only = std::is_same<C, Cfg1024I>::value;
 // every instantiation of a plan that can be launched: (MIXOP, OUTK, STREAM) x the two logarithms
 template <class C, int XLOG>
 hipError_t ensure_lds_attrs_of_plan_x() {
+    if constexpr (C::PAIR) {   // the pair plan exists for the sum-type mixes and float columns only
+        hipError_t e = ensure_lds_attr<C, 0, 0, 0, XLOG>();
+        if (e == hipSuccess) e = ensure_lds_attr<C, 0, 0, 1, XLOG>();
+        return e;
+    } else
     if constexpr (image_only<C>) {
         hipError_t e = ensure_lds_attr<C, 0, 2, 0, XLOG>();
         if (e == hipSuccess) e = ensure_lds_attr<C, 3, 2, 0, XLOG>();
@@ -1241,6 +1481,10 @@ hipError_t launch_stft_mix(const StftKArgs& ka, dim3 grid, hipStream_t s) {
 
 template <class C>
 hipError_t launch_stft(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s) {
+    if constexpr (C::PAIR) {
+        if (ka.argb || ka.idx || mixop != 0) return hipErrorInvalidValue;
+        return launch_stft_mix<C, 0>(ka, grid, s);
+    } else {
     if (ka.argb) {  // single-kernel display path
         if constexpr (image_ok<C>) {
             if (mixop == 3) return launch_stft_mix<C, 3, 2>(ka, grid, s);
@@ -1262,6 +1506,7 @@ hipError_t launch_stft(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s)
         default: return launch_stft_mix<C, 0>(ka, grid, s);
     }
     }
+    }
 }
 
 // strided multi-batch launches (STREAM == 1): the sum-mixed and the one-channel instantiations
@@ -1270,6 +1515,8 @@ hipError_t launch_stft_strided(const StftKArgs& ka, int mixop, dim3 grid, hipStr
     if constexpr (image_only<C>) return hipErrorInvalidValue;
     else {
         if (ka.argb || ka.idx) return hipErrorInvalidValue;
+        if constexpr (C::PAIR) return mixop == 0 ? launch_stft_mix<C, 0, 0, STREAM>(ka, grid, s) : hipErrorInvalidValue;
+        else
         if (mixop == 3) return launch_stft_mix<C, 3, 0, STREAM>(ka, grid, s);
         if (mixop == 0) return launch_stft_mix<C, 0, 0, STREAM>(ka, grid, s);
         return hipErrorInvalidValue;
@@ -1282,7 +1529,7 @@ hipError_t launch_stft_strided(const StftKArgs& ka, int mixop, dim3 grid, hipStr
 // jsg_stft_b.hip: JSG_STFT_PLANS below); jsg_kernels.hip reaches them through these plain functions only, so no kernel is
 // ever compiled twice and hipFuncSetAttribute always addresses the one copy that is launched.
 // ------------------------------------------------------------------------------------------------------------
-#define JSG_FOR_EACH_PLAN(X) X(Cfg512) X(Cfg1024) X(Cfg1024I) X(Cfg2048) X(Cfg2048B) X(Cfg4096) X(Cfg4096B) X(Cfg8192)
+#define JSG_FOR_EACH_PLAN(X) X(Cfg512) X(Cfg1024) X(Cfg1024I) X(Cfg2048) X(Cfg2048B) X(Cfg2048P) X(Cfg4096) X(Cfg4096B) X(Cfg8192)
 #define JSG_DECLARE_PLAN(C)                                                                   \
     hipError_t launch_##C(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s);          \
     hipError_t launch_strided_##C(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s);  \

@@ -277,12 +277,13 @@ class StftLaunch:
 
 def stft_db(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: int | None = None, mix_mode: int = 0,
             first_frame: int = 0, ring_pos: int = 0, linear_out: bool = False, blocks_per_cu: int = 0,
-            stream: int | None = None, plan_select: int = 0, exact_log: bool = False):
+            stream: int | None = None, plan_select: int = 0, exact_log: bool = False, d_tail=None):
     """Enqueue one fused STFT->dB launch.  d_in: torch CUDA float32 [C][samples]; d_out: [W][pitch] (or
-    [C][W][pitch] with mix_mode PER_CHANNEL).  Frame j starts at sample (j//feedblocks)*n + (j%feedblocks)*hop."""
+    [C][W][pitch] with mix_mode PER_CHANNEL).  Frame j starts at sample (j//feedblocks)*n + (j%feedblocks)*hop.
+    d_tail: see _stft_args (jsg_stft_args.out_tail: bin n/2 in a dense plane, columns of n/2 floats)."""
     import torch
     a = _stft_args(plan, d_in, hop, n_frames, d_out, feedblocks=feedblocks, mix_mode=mix_mode, first_frame=first_frame,
-                   ring_pos=ring_pos, linear_out=linear_out, blocks_per_cu=blocks_per_cu, plan_select=plan_select, exact_log=exact_log)
+                   ring_pos=ring_pos, linear_out=linear_out, blocks_per_cu=blocks_per_cu, plan_select=plan_select, exact_log=exact_log, d_tail=d_tail)
     if stream is None:
         stream = torch.cuda.current_stream(d_in.device).cuda_stream
     check(lib().jsg_stft_db_launch(plan._p, C.byref(a), C.c_void_p(stream)))

@@ -189,9 +189,107 @@ static void frame_power(const mplan* p, const float* x, const float* win2, float
     }
 }
 
+/* ---- the pair plan (Cfg2048P): a channel PAIR as one complex sequence z = x1 + i x2 of N points; |X1[k]|^2 + |X2[k]|^2 = (|Z[k]|^2 +
+ * |Z[N-k]|^2) / 2.  Decimation in time: E / O = the N/2-point transforms of the even / odd samples (two-stage 32 x 32 engine, the window --
+ * one real value per complex sample -- folded into the first butterfly layer: PairFirstLayer), Z[k] = E[k] + W_N^k O[k], Z[k + N/2] = E[k] -
+ * W_N^k O[k] with W_N^(k + N/4) = -i W_N^k taken from the lower half of the table.  Powers accumulated as (sum Re^2, sum Im^2). ---- */
+static void pair_half_fft(const float* x1, const float* x2, const float* winp, int h, cf* E1, cf* Y) {
+    const int M = 1024, R = 32;
+    cf t[32], a[16], b[16];
+    for (int t1 = 0; t1 < M / R; ++t1) {   /* stage 1: lane ll = t1 holds samples n = 2 (ll + 32 n1) + h */
+        cf z[32];
+        float w[32];
+        for (int n1 = 0; n1 < R; ++n1) {
+            const int n = 2 * (t1 + 32 * n1) + h;
+            z[n1].x = x1[n];
+            z[n1].y = x2[n];
+            w[n1] = winp[n];
+        }
+        for (int J = 0; J < R / 2; ++J) {
+            cf hi, d;
+            hi.x = z[J + 16].x * w[J + 16];
+            hi.y = z[J + 16].y * w[J + 16];
+            a[J].x = fmaf(z[J].x, w[J], hi.x);
+            a[J].y = fmaf(z[J].y, w[J], hi.y);
+            d.x = fmaf(z[J].x, w[J], -hi.x);
+            d.y = fmaf(z[J].y, w[J], -hi.y);
+            b[J] = mul_w_q1(J % (R / 4), R, d);
+        }
+        dft(R / 2, 0, a);
+        dft(R / 2, 1, b);
+        for (int q = 0; q < R / 2; ++q) {
+            t[2 * q] = a[q];
+            t[2 * q + 1] = b[q];
+        }
+        E1[t1] = t[0];
+        for (int k1 = 1; k1 < R; ++k1) E1[k1 * (M / R) + t1] = cmul(t[k1], tw((long long)t1 * k1, (long long)R * R));
+    }
+    for (int k1 = 0; k1 < M / R; ++k1) {   /* stage 2: no further twiddle, Y[k1 + 32 k2] */
+        for (int n2 = 0; n2 < R; ++n2) t[n2] = E1[k1 * (M / R) + n2];
+        dft(R, 0, t);
+        for (int k2 = 0; k2 < R; ++k2) Y[k1 + R * k2] = t[k2];
+    }
+}
+
+/* one column of the pair plan: channels c0 .. c0 + nch - 1 (nch even) -> out[0 .. N/2]; `hs_scale` / `divisor` as the kernel's epilogue */
+static void pair_column(const float* x, long long pitch, int c0, int nch, long long start, const float* winp, int exact_div, float scale, float divisor,
+                        int exact_db, float* out, cf* E1, cf* Y0, cf* Y1, cf* accU, cf* accV) {
+    const int N = 2048, M = 1024;
+    for (int k = 0; k < M; ++k) accU[k].x = accU[k].y = accV[k].x = accV[k].y = 0.0f;
+    for (int c = c0; c + 1 < c0 + nch; c += 2) {
+        const float* x1 = x + (long long)c * pitch + start;
+        const float* x2 = x1 + pitch;
+        pair_half_fft(x1, x2, winp, 0, E1, Y0);
+        pair_half_fft(x1, x2, winp, 1, E1, Y1);
+        for (int k = 0; k < M; ++k) {
+            const int upper = k >= M / 2;
+            const cf O = cmul(Y1[k], tw(upper ? k - M / 2 : k, N));
+            const cf E = Y0[k];
+            const cf Z = upper ? add_mi(E, O) : cf_add(E, O);
+            const cf Zm = upper ? sub_mi(E, O) : cf_sub(E, O);
+            accU[k].x = fmaf(Z.x, Z.x, accU[k].x);
+            accU[k].y = fmaf(Z.y, Z.y, accU[k].y);
+            accV[k].x = fmaf(Zm.x, Zm.x, accV[k].x);
+            accV[k].y = fmaf(Zm.y, Zm.y, accV[k].y);
+        }
+    }
+    const float U0 = accU[0].x + accU[0].y, V0 = accV[0].x + accV[0].y;
+    const float hs = 0.5f * scale;
+    for (int k = 0; k <= M; ++k) {
+        float o;
+        if (k == M) o = V0 + V0;
+        else {
+            const float U = accU[k].x + accU[k].y;
+            const float Vm = k == 0 ? U0 : accV[M - k].x + accV[M - k].y;
+            o = U + Vm;
+        }
+        o = exact_div ? (o * 0.5f) / divisor : o * hs;
+        out[k] = exact_db ? jsg_exact_db(o) : o;
+    }
+}
+
 /* mix modes as include/jsg.h (JSG_MIX_*): 0 AbsMean, 1 Max, 2 Min, 3 Left, 4 Right, 101 Sum */
 int jsg_mirror_columns(const char* plan_name, const float* x, long long pitch, int channels, int hop, int feedblocks, long long first_frame,
                        long long n_frames, const float* window, float power_scale, int mix_mode, int exact_db, float* out /* [n_frames][N/2+1] */) {
+    if (!strcmp(plan_name, "Cfg2048P")) {   /* the pair plan: sum-type mixes over an even channel count */
+        if (!x || !window || !out || channels < 2 || (channels & 1) || hop < 1 || feedblocks < 1 || (mix_mode != 0 && mix_mode != 101)) return -2;
+        const int N = 2048, M = 1024, H = M + 1;
+        float* winp = (float*)malloc(sizeof(float) * N);
+        cf* buf = (cf*)malloc(sizeof(cf) * M * 5);
+        const double amp = sqrt((double)power_scale);
+        for (int n = 0; n < N; ++n) winp[n] = (float)((double)window[n] * amp);
+        const int pow2 = (channels & (channels - 1)) == 0;
+        const int exact_div = mix_mode == 0 && !pow2;
+        const float scale = mix_mode == 0 ? 1.0f / (float)channels : 1.0f, divisor = mix_mode == 0 ? (float)channels : 1.0f;
+        const int regular = (long long)hop * feedblocks == N;
+        for (long long i = 0; i < n_frames; ++i) {
+            const long long j = first_frame + i;
+            const long long start = regular ? j * hop : (j / feedblocks) * N + (j % feedblocks) * hop;
+            pair_column(x, pitch, 0, channels, start, winp, exact_div, scale, divisor, exact_db, out + i * H, buf, buf + M, buf + 2 * M, buf + 3 * M, buf + 4 * M);
+        }
+        free(winp); free(buf);
+        return 0;
+    }
     const mplan* p = NULL;
     for (unsigned i = 0; i < sizeof kPlans / sizeof kPlans[0]; ++i)
         if (!strcmp(kPlans[i].name, plan_name)) p = &kPlans[i];

@@ -7,7 +7,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libjsg_mirror.so")
-PLANS = {512: ("Cfg512",), 1024: ("Cfg1024",), 2048: ("Cfg2048", "Cfg2048B"), 4096: ("Cfg4096", "Cfg4096B"), 8192: ("Cfg8192",)}
+PLANS = {512: ("Cfg512",), 1024: ("Cfg1024",), 2048: ("Cfg2048", "Cfg2048B", "Cfg2048P"), 4096: ("Cfg4096", "Cfg4096B"), 8192: ("Cfg8192",)}
 
 
 class _Mirror:
@@ -23,7 +23,7 @@ class _Mirror:
     def columns(self, plan, x, hop, n_frames, win, feedblocks=None, mix=0, power_scale=1.0, first_frame=0, exact_db=False):
         """plan: kernel name ("Cfg1024", "Cfg2048B", ...; what jsg_stft_kernel_name reports); x: [C][samples] float32.  Returns
         [n_frames][n/2+1] float32: mixed linear power in the GPU kernel's own operation order, or dB through the shared logarithm."""
-        n = int(plan[3:].rstrip("B"))
+        n = int(plan[3:].rstrip("BP"))
         x = np.ascontiguousarray(x, dtype=np.float32)
         win = np.ascontiguousarray(win, dtype=np.float32)
         assert win.size == n

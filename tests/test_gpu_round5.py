@@ -194,3 +194,115 @@ def test_lossless_producer_call_loses_nothing(jsg, oracle, torch_cuda):
     assert pc == (2 * (K - sum(rcs))) % W
     for s in (a, b, c):
         s.close()
+
+
+# ---- the pair plan (Cfg2048P: VERDICT r4 item 1): a channel pair as ONE complex transform, sum-type mixes over an even channel count ----
+PAIR_CASES = [  # (channels, hop, feedblocks, mix, window, signal, frames)
+    (2, 512, 4, "absmean", 1, "synth", 96), (4, 512, 4, "absmean", 1, "noise", 96), (8, 512, 4, "absmean", 1, "synth", 96),
+    (6, 1024, 2, "absmean", 3, "noise", 64), (4, 2048, 1, "sum", 0, "synth", 40), (8, 205, 10, "absmean", 2, "noise", 50),
+    (2, 512, 4, "absmean", 5, "sparse", 48), (16, 512, 4, "absmean", 4, "quiet", 32),
+]
+
+
+def _pair_signal(oracle, C, n_samples, kind, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "synth":
+        return oracle.synth_audio(C, n_samples, seed=seed)
+    if kind == "noise":
+        return rng.uniform(-1, 1, (C, n_samples)).astype(np.float32)
+    if kind == "quiet":
+        return (rng.uniform(-1, 1, (C, n_samples)) * 1e-18).astype(np.float32)
+    x = np.zeros((C, n_samples), np.float32)
+    x[:, rng.integers(0, n_samples, 7)] = 1.0
+    return x
+
+
+@pytest.mark.parametrize("C,hop,fb,mix,win_kind,signal,F", PAIR_CASES)
+def test_pair_plan_equals_the_mirror_bit_for_bit_and_the_float64_oracle_within_the_bound(jsg, oracle, mirror, torch_cuda, C, hop, fb, mix, win_kind, signal, F):
+    """plan_select = 3: Cfg2048P.  Linear power and exact-log dB against oracle/jsg_mirror.c (every bit), linear power against the float64
+    DFT of the float32 windowed frames inside the parity bound of tests/parity_util.py (the bound of every other 2048-point kernel)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from parity_util import assert_power_close
+    torch = torch_cuda
+    cap = jsg.capi
+    m = {"absmean": cap.MIX_ABSMEAN, "sum": cap.MIX_SUM}[mix]
+    n = 2048
+    last = F - 1
+    n_samples = (last // fb) * n + (last % fb) * hop + n
+    x = _pair_signal(oracle, C, n_samples, signal, seed=C + hop)
+    win = oracle.window(win_kind, n)
+    plan = jsg.Plan(n, win)
+    H, pitch = n // 2 + 1, 1056
+    d_x = torch.from_numpy(x).cuda()
+    d_lin = torch.zeros((F, pitch), device="cuda")
+    d_db = torch.zeros((F, pitch), device="cuda")
+    kw = dict(feedblocks=fb, mix_mode=m, plan_select=3)
+    assert jsg.stft_kernel_name(plan, d_x, hop, F, d_lin, **kw) == "Cfg2048P"
+    jsg.stft_db(plan, d_x, hop, F, d_lin, linear_out=True, **kw)
+    jsg.stft_db(plan, d_x, hop, F, d_db, exact_log=True, **kw)
+    torch.cuda.synchronize()
+    ref_lin = mirror.columns("Cfg2048P", x, hop, F, win, feedblocks=fb, mix=m)
+    ref_db = mirror.columns("Cfg2048P", x, hop, F, win, feedblocks=fb, mix=m, exact_db=True)
+    got_lin = d_lin[:, :H].cpu().numpy()
+    bad = got_lin.view(np.uint32) != ref_lin.view(np.uint32)
+    assert not bad.any(), (f"Cfg2048P: {int(bad.sum())} of {bad.size} power values differ from the mirror; first at {tuple(np.argwhere(bad)[0])}: "
+                           f"{got_lin[bad][0]!r} vs {ref_lin[bad][0]!r}")
+    assert (d_db[:, :H].cpu().numpy().view(np.uint32) == ref_db.view(np.uint32)).all()
+    if signal in ("synth", "noise"):
+        j = np.arange(F)
+        starts = (j // fb) * n + (j % fb) * hop
+        idx = starts[:, None] + np.arange(n)[None, :]
+        frames = (x[:, idx] * win[None, None, :]).astype(np.float32)
+        p64 = oracle.power_spectrum_f64(frames)
+        ref = oracle.mix_channels(p64.astype(np.float32), oracle.MIX_ABSMEAN).astype(np.float64) if mix == "absmean" else p64.astype(np.float32).sum(axis=0, dtype=np.float32).astype(np.float64)
+        assert_power_close(got_lin, ref, f"Cfg2048P C={C} hop={hop}")
+
+
+def test_pair_plan_selection(jsg, oracle, torch_cuda):
+    """Where the pair plan does not apply -- an odd channel count, a selecting mix, per-channel rows -- plan_select = 3 means 'automatic'
+    and today's kernels run; where it applies it is named."""
+    torch = torch_cuda
+    n, hop, F = 2048, 512, 64
+    plan = jsg.Plan(n, oracle.window(oracle.WIN_HANN, n))
+    out = torch.zeros((F, 1056), device="cuda")
+    for C, mix, want in ((3, jsg.capi.MIX_ABSMEAN, "Cfg2048"), (5, jsg.capi.MIX_SUM, "Cfg2048"), (4, jsg.capi.MIX_MAX, "Cfg2048"),
+                         (4, jsg.capi.MIX_LEFT, "Cfg2048"), (4, jsg.capi.MIX_ABSMEAN, "Cfg2048P"), (2, jsg.capi.MIX_SUM, "Cfg2048P")):
+        d_x = _rand_in(torch, (C, (F - 1) * hop + n), seed=C)
+        assert jsg.stft_kernel_name(plan, d_x, hop, F, out, feedblocks=4, mix_mode=mix, plan_select=3) == want, (C, mix)
+        jsg.stft_db(plan, d_x, hop, F, out, feedblocks=4, mix_mode=mix, plan_select=3)      # ... and runs
+    torch.cuda.synchronize()
+    # an odd count through the pair request equals the automatic choice bit for bit (it IS the automatic choice)
+    d_x = _rand_in(torch, (3, (F - 1) * hop + n), seed=9)
+    a, b = torch.zeros((F, 1056), device="cuda"), torch.zeros((F, 1056), device="cuda")
+    jsg.stft_db(plan, d_x, hop, F, a, feedblocks=4, plan_select=3)
+    jsg.stft_db(plan, d_x, hop, F, b, feedblocks=4, plan_select=0)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("C,K,F,W,pos,tail", [(8, 3, 4096, 4096, 0, False), (2, 5, 700, 800, 750, False), (4, 4, 2048, 2050, 5, True), (8, 12, 4096, 4096, 0, True)])
+def test_pair_plan_strided_batches_equal_single_launches(jsg, oracle, torch_cuda, C, K, F, W, pos, tail):
+    torch = torch_cuda
+    n, hop, M = 2048, 512, 1024
+    plan = jsg.Plan(n, oracle.window(oracle.WIN_HANN, n))
+    d_in = _rand_in(torch, (K, C, (F - 1) * hop + n), seed=K + C)
+    pitch = M if tail else 1056
+    ref = torch.full((K, W, pitch), -7.0, device="cuda")
+    got = torch.full((K, W, pitch), -7.0, device="cuda")
+    t_ref = torch.full((K, 1, W), -7.0, device="cuda") if tail else None
+    t_got = torch.full((K, 1, W), -7.0, device="cuda") if tail else None
+    kw = dict(feedblocks=4, ring_pos=pos, plan_select=3)
+    assert jsg.stft_db_strided_kernel_name(plan, d_in, hop, F, got, d_tail=t_got, **kw) == "Cfg2048P"
+    for b in range(K):
+        jsg.stft_db(plan, d_in[b], hop, F, ref[b], d_tail=(t_ref[b] if tail else None), **kw)
+    jsg.stft_db_strided(plan, d_in, hop, F, got, d_tail=t_got, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    if tail:
+        assert torch.equal(t_got, t_ref)
+        cols = (pos + torch.arange(F, device="cuda")) % W
+        lay = torch.full((W, 1056), -7.0, device="cuda")
+        jsg.stft_db(plan, d_in[0], hop, F, lay, **kw)                       # the reference layout holds the same values
+        torch.cuda.synchronize()
+        assert torch.equal(lay[:, :M], ref[0]) and torch.equal(lay[cols, M], t_ref[0, 0, cols])

@@ -68,7 +68,7 @@ def main():
                 vmem = sum(c for o, c in mx.items() if o.startswith(("global_", "buffer_", "scratch_")))
                 print(f"{short(name)}  vgpr {g('vgpr_count'):>3} spill {g('vgpr_spill_count'):>2} sgpr {g('sgpr_count'):>3} sspill {g('sgpr_spill_count'):>2} "
                       f"scratch {g('private_segment_fixed_size'):>3} lds {g('group_segment_fixed_size'):>6} | static: valu {valu} (pk {pk}) ds {lds} vmem {vmem} "
-                      f"nop {mx.get('s_nop', 0)} mov {mx.get('v_mov_b32', 0) + mx.get('v_mov_b64', 0)} swap {mx.get('v_permlane32_swap_b32', 0)}")
+                      f"nop {mx.get('s_nop', 0)} mov {mx.get('v_mov_b32_e32', 0) + mx.get('v_mov_b32_e64', 0)} swap {mx.get('v_permlane32_swap_b32_e32', 0)}")
                 if isa_pat and re.search(isa_pat, short(name)):
                     print(dis.split(f"<{name}>:")[1].split("\n\n")[0][:200000])
 
