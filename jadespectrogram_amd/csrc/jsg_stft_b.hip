@@ -1,5 +1,7 @@
 // Translation unit B of the STFT kernels: the two 4096-point plans (default machine scheduler: see jsg_stft_a.hip).
+#ifndef JSG_X_B_SCALAR_TWIDDLE   // (variant builds: A/B of the scalar form in this unit)
 #define JSG_TWIDDLE_CONST_VGPR 1   // see mul_w_q1
+#endif
 #include "jsg_stft_kernel.h"
 
 namespace jsg {

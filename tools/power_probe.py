@@ -13,6 +13,11 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import jadespectrogram_amd as jsg
+if os.environ.get("SP_LIB"):          # a variant build (python -m jadespectrogram_amd._build --variant NAME ...; round-4-tree variants: ABI 5)
+    jsg.capi.LIB_PATH = os.path.abspath(os.environ["SP_LIB"])
+    if os.environ.get("SP_ABI5"):     # a library built from the round-4 tree: it lacks the entry points of ABI 6 (the argument structs only grew at the end)
+        jsg.capi.SIGNATURES.pop("jsg_process_block_wait", None)
+TAG = os.environ.get("PW_TAG", os.path.basename(os.environ.get("SP_LIB", "product")))
 
 SECONDS = float(os.environ.get("PW_SECONDS", 6))
 ONLY = [s for s in os.environ.get("PW_ONLY", "").split(",") if s]
@@ -43,9 +48,14 @@ def watch(run_once, bytes_per_call, units_per_call, label):
         e1.record(st)
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
-    print(json.dumps({"workload": label, "seconds": round(ms / 1e3, 2), "GBps_algorithmic": round(bytes_per_call * calls / ms / 1e6, 1),
-                      "frac_of_8TBps": round(bytes_per_call * calls / ms / 1e6 / 8000, 4), "units_per_s": round(units_per_call * calls / ms * 1e3, 1),
-                      **w.summary(), "cap_W": HW.cap_W()}), flush=True)
+    summ = w.summary()
+    ups = units_per_call * calls / ms * 1e3
+    watts = summ.get("socket_W_median")
+    print(json.dumps({"build": TAG, "workload": label, "seconds": round(ms / 1e3, 2), "GBps_algorithmic": round(bytes_per_call * calls / ms / 1e6, 1),
+                      "frac_of_8TBps": round(bytes_per_call * calls / ms / 1e6 / 8000, 4), "units_per_s": round(ups, 1),
+                      "units_per_joule": (round(ups / watts, 1) if watts and ups else None),
+                      "GB_algorithmic_per_joule": (round(bytes_per_call * calls / ms / 1e6 / watts, 3) if watts else None),
+                      **summ, "cap_W": HW.cap_W()}), flush=True)
 
 
 lib = jsg.capi.lib()
@@ -68,9 +78,9 @@ if want("copy"):
     del pool
 
 
-def stft_case(label, n, hop, C, F, K, mix=None, linear=False, bpc=0, plan_select=0):
+def stft_case(label, n, hop, C, F, K, mix=None, linear=False, bpc=0, plan_select=0, tail=False):
     H = n // 2 + 1
-    pitch = (H + 31) // 32 * 32
+    pitch = n // 2 if tail else (H + 31) // 32 * 32
     ns = (F * hop + n - hop + 3) // 4 * 4
     plan = jsg.Plan(n, jsg.window(jsg.capi.WIN_HANN, n))
     d_in = torch.empty((K, C, ns), dtype=torch.float32, device="cuda").uniform_(-0.5, 0.5)
@@ -84,6 +94,8 @@ def stft_case(label, n, hop, C, F, K, mix=None, linear=False, bpc=0, plan_select
         kw["blocks_per_cu"] = bpc
     if plan_select:
         kw["plan_select"] = plan_select
+    if tail:
+        kw["d_tail"] = torch.empty((K, 1, F), dtype=torch.float32, device="cuda")
     watch(lambda st: jsg.stft_db_strided(plan, d_in, hop, F, d_out, stream=st.cuda_stream, **kw),
           K * (C * F * hop * 4 + F * H * 4), K * F * C, label)
 
@@ -92,6 +104,12 @@ if want("c2"):
     stft_case("C2: N=1024 hop 512 mono, 64 x 4096 frames per dispatch", 1024, 512, 1, 4096, 64)
 if want("c2lin"):
     stft_case("C2 geometry, linear power out (no logarithm)", 1024, 512, 1, 4096, 64, linear=True)
+if want("c2tail"):
+    stft_case("C2, tail-plane column layout", 1024, 512, 1, 4096, 64, tail=True)
+if want("c3a"):
+    stft_case("C3 geometry, three-stage plan Cfg2048 (plan_select 1)", 2048, 512, 8, 4096, 12, mix=jsg.capi.MIX_ABSMEAN, plan_select=1)
+if want("c3p"):
+    stft_case("C3 geometry, pair plan Cfg2048P (plan_select 3)", 2048, 512, 8, 4096, 12, mix=jsg.capi.MIX_ABSMEAN, plan_select=3)
 if want("c3"):
     stft_case("C3: N=2048 hop 512, 8 channels AbsMean, 12 x 4096 columns per dispatch", 2048, 512, 8, 4096, 12, mix=jsg.capi.MIX_ABSMEAN)
 if want("c512"):
