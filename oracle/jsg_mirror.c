@@ -100,6 +100,71 @@ static void dft_win(int R, cf* x, const cf* w) {
     }
 }
 
+/* ---- split-radix register DFTs for R = 16 and 32 (jsg_stft_kernel.h: mul_w32, SrOdd, sr_rest, sr_dft, sr_dft_win); R <= 8: the radix-2 code ---- */
+/* v * exp(-2 pi i E / 32): first-quadrant constants, the quadrant E / 8 in the signs and the component order; t = (+-c v_a, +-c v_b), r = fma(+-s v_c, .) */
+static inline cf mul_w32(int E, cf v) {
+    const int e = E % 8, q = E / 8;
+    const float c = kCos32[e], sn = kSin32[e];
+    cf r;
+    if (q == 0) {
+        const float tx = v.x * c, ty = v.y * c;
+        r.x = fmaf(v.y, sn, tx);
+        r.y = fmaf(-v.x, sn, ty);
+    } else if (q == 1) {
+        const float tx = v.y * c, ty = -v.x * c;
+        r.x = fmaf(-v.x, sn, tx);
+        r.y = fmaf(-v.y, sn, ty);
+    } else if (q == 2) {
+        const float tx = -v.x * c, ty = -v.y * c;
+        r.x = fmaf(-v.y, sn, tx);
+        r.y = fmaf(v.x, sn, ty);
+    } else {
+        const float tx = -v.y * c, ty = v.x * c;
+        r.x = fmaf(v.x, sn, tx);
+        r.y = fmaf(v.y, sn, ty);
+    }
+    return r;
+}
+static void sr_dft(int R, cf* x);
+static void sr_rest(int R, cf* a, const cf* d, cf* x) {
+    cf z1[8], z3[8];
+    for (int n = 0; n < R / 4; ++n) {
+        const cf p = d[n], q = d[n + R / 4];
+        const cf u = add_mi(p, q), w = sub_mi(p, q);
+        z1[n] = n == 0 ? u : mul_w32(n * (32 / R), u);
+        z3[n] = n == 0 ? w : mul_w32((3 * n * (32 / R)) % 32, w);
+    }
+    sr_dft(R / 2, a);
+    sr_dft(R / 4, z1);
+    sr_dft(R / 4, z3);
+    for (int k = 0; k < R / 2; ++k) x[2 * k] = a[k];
+    for (int k = 0; k < R / 4; ++k) {
+        x[4 * k + 1] = z1[k];
+        x[4 * k + 3] = z3[k];
+    }
+}
+static void sr_dft(int R, cf* x) {
+    if (R <= 8) { dft(R, 0, x); return; }
+    cf a[16], d[16];
+    for (int J = 0; J < R / 2; ++J) {
+        a[J] = cf_add(x[J], x[J + R / 2]);
+        d[J] = cf_sub(x[J], x[J + R / 2]);
+    }
+    sr_rest(R, a, d, x);
+}
+static void sr_dft_win(int R, cf* x, const cf* w) {
+    if (R <= 8) { dft_win(R, x, w); return; }
+    cf a[16], d[16];
+    for (int J = 0; J < R / 2; ++J) {
+        const cf hi = x[J + R / 2];
+        a[J].x = fmaf(x[J].x, w[J].x, hi.x);
+        a[J].y = fmaf(x[J].y, w[J].y, hi.y);
+        d[J].x = fmaf(x[J].x, w[J].x, -hi.x);
+        d[J].y = fmaf(x[J].y, w[J].y, -hi.y);
+    }
+    sr_rest(R, a, d, x);
+}
+
 typedef struct { const char* name; int N, R1, R2, R3, L, twf; } mplan;
 static const mplan kPlans[] = {   /* jsg_stft_kernel.h: Cfg512 .. Cfg8192 (radices, lanes per frame, factorised tables) */
     {"Cfg512", 512, 8, 8, 4, 32, 0},     {"Cfg1024", 1024, 8, 8, 8, 64, 0},    {"Cfg2048", 2048, 16, 8, 8, 64, 1}, {"Cfg2048B", 2048, 32, 32, 1, 32, 0},
@@ -132,7 +197,7 @@ static void frame_power(const mplan* p, const float* x, const float* win2, float
                 t[n1].y = x[2 * n + 1] * win2[2 * n + 1];
             }
         }
-        dft_win(R1, t, wl);
+        sr_dft_win(R1, t, wl);
         E1[t1] = t[0];
         for (int k1 = 1; k1 < R1; ++k1) E1[k1 * (M / R1) + t1] = cmul(t[k1], tw((long long)(t1 / R3) * k1, (long long)R1 * R2));
     }
@@ -140,7 +205,7 @@ static void frame_power(const mplan* p, const float* x, const float* win2, float
     for (int t2 = 0; t2 < M / R2; ++t2) {
         const int k1 = t2 / R3, n3 = t2 % R3;
         for (int n2 = 0; n2 < R2; ++n2) t[n2] = E1[k1 * (M / R1) + n2 * R3 + n3];
-        dft(R2, 0, t);
+        sr_dft(R2, t);
         if (two_stage) {
             for (int k2 = 0; k2 < R2; ++k2) Z[k1 + R1 * k2] = t[k2];
             continue;
@@ -157,7 +222,7 @@ static void frame_power(const mplan* p, const float* x, const float* win2, float
         for (int t3 = 0; t3 < R1 * R2; ++t3) {
             const int k1 = t3 % R1, k2 = t3 / R1;
             for (int n3 = 0; n3 < R3; ++n3) t[n3] = E2[(k1 * R2 + k2) * R3 + n3];
-            dft(R3, 0, t);
+            sr_dft(R3, t);
             for (int k3 = 0; k3 < R3; ++k3) Z[t3 + R1 * R2 * k3] = t[k3];
         }
     Z[M] = Z[0];
@@ -226,7 +291,7 @@ static void pair_half_fft(const float* x1, const float* x2, const float* winp, i
     }
     for (int k1 = 0; k1 < M / R; ++k1) {   /* stage 2: no further twiddle, Y[k1 + 32 k2] */
         for (int n2 = 0; n2 < R; ++n2) t[n2] = E1[k1 * (M / R) + n2];
-        dft(R, 0, t);
+        dft(R, 0, t);   /* (the pair plan keeps the radix-2 transforms) */
         for (int k2 = 0; k2 < R; ++k2) Y[k1 + R * k2] = t[k2];
     }
 }
