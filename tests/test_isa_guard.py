@@ -57,15 +57,20 @@ def test_counted_wait_matches_the_emitted_frame_loads(tmp_path):
     for name, body in _functions(text):
         if "stft_db_kernel" not in name and "stft_image_kernel" not in name:
             continue
-        # Cfg<N, R1, R2, R3, L, S1, AX, AY, AZ, WPB, TLOC, WPS, FPW, ABL, TWF>
-        m = re.search(r"3CfgI(.*?)EE", name)
+        # Cfg<N, R1, R2, R3, L, S1, AX, AY, AZ, WPB, TLOC, WPS, FPW, HX, TWF, PAIR>
+        m = re.search(r"3CfgI((?:Li\d+E)+)E", name)
         vals = [int(v) for v in re.findall(r"Li(\d+)E", m.group(1))]
         n, lanes, tloc, fpw = vals[0], vals[4], vals[10], vals[12]
+        pair = len(vals) > 15 and vals[15] == 1
         if tloc != 1:
             continue
-        if re.search(r"EELi\dELi\dELi2EEEv", name):    # STREAM == 2 (staged input): its own guard below
+        if re.search(r"EELi\dELi\dELi2ELi\dEEEv", name):    # STREAM == 2 (staged input): its own guard below
             continue
         expect = (n // 2 // lanes) * fpw
+        if pair:
+            # the pair plan loads 2 P = 64 dwords (one per channel and value); the counter names 63 at most, so its wait also retires the
+            # oldest frame load: 64 loads between the last table piece and vmcnt(63)
+            loads, expect = 2 * expect, 63
         dma = [i for i, ins in enumerate(body) if ins.startswith("global_load_lds_dwordx4") or (ins.startswith("buffer_load_dwordx4") and " lds" in ins)]
         assert dma, f"{name}: no LDS-DMA table pieces found"
         bar = next(i for i, ins in enumerate(body) if ins.startswith("s_barrier"))
@@ -77,9 +82,11 @@ def test_counted_wait_matches_the_emitted_frame_loads(tmp_path):
         assert mm, f"{name}: expected the counted wait in front of the first s_barrier, found '{w}'"
         assert int(mm.group(1)) == expect, f"{name}: waits for vmcnt({mm.group(1)}), the plan has {expect} frame loads"
         between = [ins for ins in body[last_dma + 1:bar - 1] if VMEM.match(ins)]
-        assert len(between) == expect, (f"{name}: {len(between)} vector-memory instructions between the last table piece and "
-                                        f"s_waitcnt vmcnt({expect}): {between}")
-        assert all(ins.startswith("global_load_dwordx2") for ins in between), f"{name}: unexpected frame-load form {sorted(set(between))[:3]}"
+        want = loads if pair else expect
+        assert len(between) == want, (f"{name}: {len(between)} vector-memory instructions between the last table piece and "
+                                      f"s_waitcnt vmcnt({expect}): {between}")
+        form = "global_load_dword " if pair else "global_load_dwordx2"
+        assert all(ins.startswith(form) for ins in between), f"{name}: unexpected frame-load form {sorted(set(between))[:3]}"
         checked += 1
     assert checked >= 60, f"only {checked} instantiations checked"   # 7 plans x (6 + 2 strided) + the ARGB-out forms of 1024 and 4096 "B"
 
@@ -94,9 +101,9 @@ def test_staged_kernels_counted_waits(tmp_path):
     text = _disassemble(tmp_path)
     checked = 0
     for name, body in _functions(text):
-        if "stft_db_kernel" not in name or not re.search(r"EELi\dELi\dELi2EEEv", name):
+        if "stft_db_kernel" not in name or not re.search(r"EELi\dELi\dELi2ELi\dEEEv", name):
             continue
-        m = re.search(r"3CfgI(.*?)EE", name)
+        m = re.search(r"3CfgI((?:Li\d+E)+)E", name)
         vals = [int(v) for v in re.findall(r"Li(\d+)E", m.group(1))]
         n, lanes = vals[0], vals[4]
         per_column = n // 2 // lanes + 1
