@@ -178,7 +178,7 @@ def test_mirror_of_the_gpu_arithmetic_is_within_the_parity_bound_of_the_float64_
     from parity_util import assert_power_close
     m = mirror_mod.load()
     for n, plans in mirror_mod.PLANS.items():
-        for hop, C, win_kind in ((n // 2, 1, oracle.WIN_HANN), (n // 4, 3, oracle.WIN_BLACKMANHARRIS)):
+        for hop, C, win_kind in ((n // 2, 1, oracle.WIN_HANN), (n // 4, 3, oracle.WIN_BLACKMANHARRIS), (n // 4, 2, oracle.WIN_HANN), (n // 2, 8, oracle.WIN_FLATTOP)):
             F = 12
             x = oracle.synth_audio(C, (F - 1) * hop + n, seed=n + C)
             win = oracle.window(win_kind, n)
@@ -186,6 +186,10 @@ def test_mirror_of_the_gpu_arithmetic_is_within_the_parity_bound_of_the_float64_
             frames = (x[:, idx] * win[None, None, :]).astype(np.float32)
             ref = oracle.mix_channels(oracle.power_spectrum_f64(frames).astype(np.float32), oracle.MIX_ABSMEAN).astype(np.float64)
             for plan in plans:
+                if plan.endswith("P") and C % 2:      # the pair plan transforms channel PAIRS: even channel counts only
+                    continue
+                if not plan.endswith("P") and C in (2, 8) and n != 2048:   # (the extra even-count cases are there for the pair plan)
+                    continue
                 got = m.columns(plan, x, hop, F, win, feedblocks=n // hop, mix=oracle.MIX_ABSMEAN)
                 assert_power_close(got, ref, f"mirror {plan} C={C}")
 
