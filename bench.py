@@ -169,7 +169,7 @@ def cpu_baseline(c, seconds_budget: float = 10.0):
     return res
 
 
-# Vector instructions per FFT of the kernels the configurations time (SQ_INSTS_VALU / FFTs, profiles/r04_*_hbm_traffic.json ->
+# Vector instructions per FFT of the kernels the configurations time (SQ_INSTS_VALU / FFTs, profiles/r05_*_hbm_traffic.json ->
 # derived) and the shader clock the chip holds under that load (C3: SQ_WAVE_CYCLES x 4 / waves = 67.7 k cycles per wave over a
 # 40.4 us dispatch = 1.68 GHz -- well under the 2.4 GHz maximum: packed-math kernels are power-limited): the issue roof of the
 # compute-bound configurations (a wave64 VALU instruction holds its SIMD for 4 cycles; 256 CUs x 4 SIMDs).
@@ -684,10 +684,10 @@ def main():
         achieved = algo / (dispatch_us * 1e-6) / 1e9
         conc = algo * dps * args.steps / wall / 1e9
         # HBM traffic (PMC) and the tracer's per-dispatch duration come from the rocprofv3 passes of tools/profile_bench.sh
-        # (profiles/r04_<cfg>_hbm_traffic.json): bench.py does not run counters itself.  The file carries the hash of the kernel sources
+        # (profiles/r05_<cfg>_hbm_traffic.json): bench.py does not run counters itself.  The file carries the hash of the kernel sources
         # it was recorded with; when that differs from this build's the figures are flagged as stale.
         traffic, tsrc, rocprof_us = None, None, None
-        prof = os.path.join(ROOT, "profiles", f"r04_{args.config}_hbm_traffic.json")
+        prof = os.path.join(ROOT, "profiles", f"r05_{args.config}_hbm_traffic.json")
         if os.path.exists(prof) and strided:
             try:
                 pj = json.load(open(prof))
