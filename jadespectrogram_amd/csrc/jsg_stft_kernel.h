@@ -1417,20 +1417,51 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                         }
                         tl_row = a.tail + (long long)trow * a.ring_w;
                     }
+                    if constexpr (L <= 64) {
+                        // Whole 128-byte lines.  The lower half of the column (bins k = lane + 64 r) starts every instruction on a line.  The
+                        // upper half is the mirror, bins M - k: as the registers hold them an instruction would cover bins M - 64 r - 63 ..
+                        // M - 64 r -- 252 bytes of two lines plus FOUR bytes (lane 0: bin M - 64 r) of a third, which the previous
+                        // instruction fills: every such line reached memory as a 124-byte and a 4-byte piece (round 5 counters: writes
+                        // 1.023 x the column bytes with or without the tail plane).  So lane 0 takes the value of the NEXT register -- bin
+                        // M - 64 (r + 1), the low end of this instruction's two lines -- and the last instruction's lane 0 the self-paired
+                        // bin M/2 (accNy, held by every lane): bins M - 64 r - 64 .. M - 64 r - 1 per instruction, and no separate store
+                        // for bin M/2.  Bin M itself (lane 0 of the first register) goes to the tail plane, or alone into the column's
+                        // last line.  Which lane stores a value changes, no value does.
+                        constexpr int RS = L == 32 ? 2 : 1;                 // registers between consecutive windows of one frame
+                        float nyA = accNy[f], nyB = accNy[f];               // bin M/2 of the frame(s) of this wavefront
+                        if constexpr (L == 32) {
+                            nyA = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(accNy[f]), 0));
+                            nyB = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(accNy[f]), 32));
+                        }
+                        const int lwu = lw == 0 ? 64 : lw;                  // lane 0 stores 64 bins further down (one select, not one per register)
+#pragma unroll
+                        for (int rho = 0; rho < P / 2; ++rho) {
+                            const bool fb = L == 32 && (rho & 1);           // the upper frame of a two-frame wavefront
+                            float* d = fb ? dstB : dstA;
+                            const int k = lw + LW * (rho / RS);
+                            __builtin_nontemporal_store(acc[f][rho].x, &d[k]);
+                            const float nxt = rho + RS < P / 2 ? acc[f][rho + RS].y : (fb ? nyB : nyA);
+                            const float up = lw == 0 ? nxt : acc[f][rho].y;
+                            __builtin_nontemporal_store(up, &d[M - (lwu + LW * (rho / RS))]);
+                            if (rho / RS == 0 && lw == 0) {                 // bin M
+                                if (tl_row) tl_row[fb ? colB : colA] = acc[f][rho].y;   // (plain store: the pieces of 32 columns meet in L2)
+                                else __builtin_nontemporal_store(acc[f][rho].y, &d[M]);
+                            }
+                        }
+                    } else {
 #pragma unroll
                     for (int rho = 0; rho < P / 2; ++rho) {
-                        float* d = (L == 32 && (rho & 1)) ? dstB : dstA;
-                        const int k = lw + LW * (L == 32 ? rho / 2 : rho);
+                        float* d = dstA;
+                        const int k = lw + LW * rho;
                         __builtin_nontemporal_store(acc[f][rho].x, &d[k]);
-                        if ((L == 32 ? rho / 2 : rho) == 0 && tl_row) {   // this instruction's lane k == 0 holds bin M = N/2
-                            // a PLAIN store: the 4-byte pieces of the 32 columns that share a 128-byte line of the plane (neighbouring
-                            // workgroups, same XCD) meet in L2 and leave as one line
-                            if (k == 0) tl_row[(L == 32 && (rho & 1)) ? colB : colA] = acc[f][rho].y;
+                        if (rho == 0 && tl_row) {   // this instruction's lane k == 0 holds bin M = N/2
+                            if (k == 0) tl_row[colA] = acc[f][rho].y;
                             else __builtin_nontemporal_store(acc[f][rho].y, &d[M - k]);
                         } else
                         __builtin_nontemporal_store(acc[f][rho].y, &d[M - k]);
                     }
-                    if (L <= 64 || ll == 0) __builtin_nontemporal_store(accNy[f], &dst[M / 2]);   // L <= 64: uniform over the frame's lanes
+                    if (ll == 0) __builtin_nontemporal_store(accNy[f], &dst[M / 2]);
+                    }
                 }
 #pragma unroll
                 for (int m = 0; m < P / 2; ++m) acc[f][m] = cf{init, init};
