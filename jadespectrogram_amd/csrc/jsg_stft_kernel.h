@@ -1383,10 +1383,16 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                     unsigned char* icA = a.idx + (long long)colA * a.idx_pitch;
                     unsigned char* icB = a.idx + (long long)colB * a.idx_pitch;
                     unsigned char* ic = a.idx + (long long)col * a.idx_pitch;
+                    // The lane offset is made opaque HERE: left visible, the 64-bit per-lane store addresses are loop invariants which the
+                    // compiler computes once in the prologue and keeps for the whole kernel -- in Cfg4096B's index-out instantiation (254
+                    // VGPRs) they were what it spilled (4 VGPRs, 20 bytes of scratch, rounds 3-4).  Recomputing them per column is a
+                    // handful of integer adds.
+                    int lwo = lw;
+                    asm volatile("" : "+v"(lwo));
 #pragma unroll
                     for (int rho = 0; rho < P / 2; ++rho) {
                         unsigned char* d = (L == 32 && (rho & 1)) ? icB : icA;
-                        const int k = lw + LW * (L == 32 ? rho / 2 : rho);
+                        const int k = lwo + LW * (L == 32 ? rho / 2 : rho);
                         int ix_, iy_;
                         color_index2(acc[f][rho], a.vmin, a.vmax, a.top, a.mult, a.n_colors, ix_, iy_);
                         d[k] = (unsigned char)ix_;
