@@ -296,6 +296,22 @@ def parity_report(jsg, c, plan, d_in_host, win):
     img_cols = d_img.cpu().numpy().view(np.uint32)[::-1, :].T[cols]
     fused_differs = int((img_cols != lut[got_idx]).sum())
     db_err = np.abs(d_db[:, :H].cpu().numpy()[cols].astype(np.float64) - oracle.to_db(ref_mixed32).astype(np.float64))
+    # the bit-reproducible mode on the SAME display launch (jsg_stft_args.exact_log): the image of jsg_stft_image_launch against the CPU
+    # mirror of the kernel (oracle/jsg_mirror.c: its float32 arithmetic and the shared logarithm) -> CColorPalette -- 0 flips expected
+    exact_flips = None
+    try:
+        from oracle import mirror as mirror_mod
+        mm = mirror_mod.load()
+        d_img_x = torch.zeros((H, F), dtype=torch.int32, device="cuda")
+        jsg.stft_image(plan, d_x, hop, F, d_lut, -50.0, 50.0, d_img_x, d_scr, feedblocks=n // hop, mix_mode=mix, exact_log=True)
+        torch.cuda.synchronize()
+        sub = cols[:: max(1, len(cols) // 128)]                                     # (a spread of columns: the mirror is scalar C)
+        mdb = np.stack([mm.columns(kernel, x, hop, 1, win, feedblocks=n // hop, mix=0, first_frame=int(cc), exact_db=True)[0] for cc in sub])
+        want = (lut[pal.index(mdb).astype(np.uint8)])
+        got_x = d_img_x.cpu().numpy().view(np.uint32)[::-1, :].T[sub]
+        exact_flips = {"pixels_differing": int((got_x != want).sum()), "pixels_checked": int(want.size), "columns_checked": int(len(sub))}
+    except Exception as e:   # a reported figure, never a reason to lose the bench line
+        exact_flips = {"error": f"{type(e).__name__}: {e}"[:200]}
     return {"kernel": kernel, "launch_checked": f"{F} columns x {C} channel(s), automatic kernel selection (the timed geometry)",
             "columns_checked_against_float64": int(len(cols)), "bins_checked": int(rel.size),
             "frac_bins_rel_power_err_gt_1e-5": float(bad.mean()),
@@ -306,6 +322,7 @@ def parity_report(jsg, c, plan, d_in_host, win):
             "max_abs_db_err": float(db_err.max()),
             "colour_index_flips_end_to_end": flips, "pixels_checked": int(got_idx.size),
             "fused_image_pixels_differing_from_two_kernel_image": fused_differs,
+            "exact_log_display_launch_vs_cpu_mirror": exact_flips,
             "note": "float64 DFT of the float32 windowed frames is the yardstick; indices: Jade, 256 colours, -50..50 dB"}
 
 
@@ -401,7 +418,8 @@ def run_extra_config(cfg):
                 "roofline": {k: j["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_source", "avg_dispatch_us", "algorithmic_bytes_per_dispatch",
                                                            "timed_region_frac", "frac_rocprof", "traffic", "second_roof") if k in j["roofline"]},
                 "parity": {k: j["parity"][k] for k in ("kernel", "frac_bins_rel_power_err_gt_1e-5", "max_err_relative_to_frame_peak", "colour_index_flips_end_to_end",
-                                                       "pixels_checked", "strided_pixels_differing_from_single_launches", "strided_columns_differing_from_single_launches")
+                                                       "pixels_checked", "exact_log_display_launch_vs_cpu_mirror", "strided_pixels_differing_from_single_launches",
+                                                       "strided_columns_differing_from_single_launches")
                            if k in j.get("parity", {})},
                 "power": ({"cap_W": j["power"].get("cap_W"), "path_sustained": j["power"].get("path_sustained")} if j.get("power") else None)}
     except Exception as e:   # a reported figure, never a reason to lose the bench line
