@@ -140,7 +140,8 @@ typedef struct jsg_stft_args {
     int32_t ring_width;
     int32_t ring_pos;
     int32_t linear_out;      /* 0: dB = 10*log10(p + 1e-11f) (the reference's column); 1: mixed linear power p */
-    int32_t blocks_per_cu;   /* 0: default (up to 8 workgroups per CU, the rest of the frames is looped over); smaller values make
+    int32_t blocks_per_cu;   /* 0: default (up to 8 workgroups per CU -- 16 or 32 in strided multi-batch launches of the small-workgroup plans --
+                                the rest of the frames is looped over); smaller values make
                                 fewer, longer-lived workgroups that prefetch their next frame -- better when several
                                 launches run concurrently, worse for one launch alone */
     int64_t in_samples;      /* floats of every channel row that may be read; the launch is refused (JSG_ERR_INVALID) when
@@ -225,6 +226,13 @@ JSG_API int jsg_stft_db_strided_kernel_name(const jsg_plan* plan, const jsg_stft
 JSG_API int jsg_db_from_power_launch(const float* power, float* out, int64_t count, float divisor, void* stream);
 /* ... with the logarithm of jsg_stft_args.exact_log (1) instead of the hardware unit (0) */
 JSG_API int jsg_db_from_power_launch_ex(const float* power, float* out, int64_t count, float divisor, int exact_log, void* stream);
+
+/* The reference's dense column shape out of the tail-plane layout (jsg_stft_args.out_tail): dst[col*dst_pitch + bin] for bin < height - 1 from
+ * db[col*db_pitch + bin], and dst[col*dst_pitch + height - 1] from tail[col], col < n_columns (one ring / one row of the plane; height = n/2 + 1).
+ * What Spectrogram::getMem hands out (m_mem[col][bin], Spectrogram.h:144, Spectrogram.cpp:295-331) for callers that computed in whole-line
+ * columns.  Device pointers; db_pitch >= height - 1, dst_pitch >= height. */
+JSG_API int jsg_columns_from_tail_layout_launch(const float* db, int64_t db_pitch, const float* tail, int n_columns, int height, float* dst,
+                                        int64_t dst_pitch, void* stream);
 
 /* Roofline calibration (no reference counterpart): a tuned float4 streaming copy of `bytes` bytes (multiple of 16, 16-byte aligned
  * device pointers), non-temporal loads and stores, one thread per 16 bytes.  bench.py times it on buffers that rotate over > 1 GB to

@@ -76,6 +76,7 @@ SIGNATURES = {
     "jsg_stft_db_launch_strided": (C.c_int, [_P, C.POINTER(StftArgs), C.c_int, C.c_int64, C.c_int64, _P]),
     "jsg_stft_db_strided_kernel_name": (C.c_int, [_P, C.POINTER(StftArgs), C.c_int, C.c_int64, C.c_char_p, C.c_int]),
     "jsg_calib_copy_launch": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "jsg_columns_from_tail_layout_launch": (C.c_int, [_P, C.c_int64, _P, C.c_int, C.c_int, _P, C.c_int64, _P]),
     "jsg_colormap_launch": (C.c_int, [C.POINTER(ColormapArgs), _P]),
     "jsg_stft_image_launch": (C.c_int, [_P, C.POINTER(StftImageArgs), _P]),
     "jsg_stft_image_needs_scratch": (C.c_int, [_P, C.POINTER(StftImageArgs)]),

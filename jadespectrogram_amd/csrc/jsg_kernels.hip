@@ -152,6 +152,17 @@ __global__ __launch_bounds__(256) void db_from_power_kernel(const float* p, floa
     }
 }
 
+// jsg_columns_from_tail_layout_launch: the reference's dense [W][n/2+1] shape (m_mem[col][bin], Spectrogram.h:144) out of the tail-plane
+// layout of jsg_stft_args.out_tail -- columns of n/2 floats + a plane of bin n/2.  One workgroup per column, 16 bytes per thread and step.
+__global__ __launch_bounds__(256) void tail_merge_kernel(const float* __restrict__ db, long long db_pitch, const float* __restrict__ tail, int half,
+                                                         float* __restrict__ dst, long long dst_pitch) {
+    const long long col = blockIdx.x;
+    const float* src = db + col * db_pitch;
+    float* out = dst + col * dst_pitch;
+    for (int k = threadIdx.x; k < half; k += 256) out[k] = src[k];
+    if (threadIdx.x == 0) out[half] = tail[col];
+}
+
 // roofline calibration (jsg_calib_copy_launch): the float4 streaming copy that reaches the most on an MI355X -- one thread per 16 bytes,
 // non-looping grid (the dispatcher hands the workgroups out in address order: the access front stays tight), non-temporal loads and
 // stores (tools/copy_roof.hip: 6.4-6.5 TB/s read + written at >= 0.5 GB, 6.3 at 134 MB; grid-stride forms 4.5-6.3)
@@ -470,7 +481,21 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     // workgroups per CU of the grid; the rest of the frames is looped over.  The "B" plans hold one workgroup per CU: a grid of
     // exactly that many keeps the tables and the prefetch pipeline alive across a workgroup's frames (16 384 mono 4096-point
     // frames: 65 vs 79 us with a grid of 8 per CU); the other plans do best with more workgroups than are resident.
-    const int bpc = g->blocks_per_cu > 0 ? g->blocks_per_cu : (blocks_per_cu_env > 0 ? blocks_per_cu_env : ((plan_b || plan_p) ? 1 : 8));
+    // Strided multi-batch launches of the small-workgroup plans do better with MORE, shorter-lived workgroups than fit a CU at once (five
+    // four-wave workgroups of the 1024-point plan, three of the others): the hardware dispatcher hands the later ones out as the earlier ones
+    // finish -- closer to address order, and the end of the dispatch is balanced -- where a grid of 8 per CU runs as one full round of resident
+    // workgroups followed by a 60 %-full one.  Measured round 5 (tools/tail_probe.py TP_BPC, interleaved, us per dispatch 8 -> 16 -> 32 per
+    // CU): C2 212.7 -> 204.0 -> 205.2 (reference layout 209.4 -> 204.0 -> 204.2), 512 points hop 512 143.2 -> 139.2 -> 135.6, hop 256 103.0
+    // -> 98.2 -> 98.3, 2048 points mono 100.8 -> 97.2 -> 101.6, 1024 points 8 channels mixed 161.1 -> 159.8 -> 164.6, 8192 points 94.6 ->
+    // 100.9.  (Round 4 had found 32 per CU behind 8 with the eight-wave workgroups and the old remap.)
+    int bpc_default = 8;
+    if (bs) {
+        const int ncol = ka.per_channel ? 1 : ka.c_end - ka.c_begin;
+        if (plan->n == 512) bpc_default = 32;
+        else if (plan->n == 1024) bpc_default = ncol == 1 ? 32 : 16;
+        else if (plan->n == 2048) bpc_default = 16;
+    }
+    const int bpc = g->blocks_per_cu > 0 ? g->blocks_per_cu : (blocks_per_cu_env > 0 ? blocks_per_cu_env : ((plan_b || plan_p) ? 1 : bpc_default));
     long long max_blocks = (long long)n_cu * bpc / ny;     // resident workgroups; the rest is looped over
     if (max_blocks < 64) max_blocks = 64;
     static const int max_blocks_env = dev_knob_int("JSG_STFT_MAX_BLOCKS");
@@ -868,6 +893,18 @@ int jsg_db_from_power_launch_ex(const float* power, float* out, int64_t count, f
                        reinterpret_cast<hipStream_t>(stream), power, out, (long long)count, divisor, exact_log ? 1 : 0);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return jsg_fail_hip(err, "jsg_db_from_power_launch");
+    return JSG_OK;
+}
+
+int jsg_columns_from_tail_layout_launch(const float* db, int64_t db_pitch, const float* tail, int n_columns, int height, float* dst, int64_t dst_pitch,
+                                        void* stream) {
+    if (n_columns == 0) return JSG_OK;
+    if (!db || !tail || !dst || n_columns < 0 || height < 2 || db_pitch < height - 1 || dst_pitch < height)
+        return jsg_fail(JSG_ERR_INVALID, "jsg_columns_from_tail_layout_launch: bad argument (db_pitch >= height - 1, dst_pitch >= height)");
+    hipLaunchKernelGGL(tail_merge_kernel, dim3((unsigned)n_columns), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), db, (long long)db_pitch, tail,
+                       height - 1, dst, (long long)dst_pitch);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return jsg_fail_hip(err, "jsg_columns_from_tail_layout_launch");
     return JSG_OK;
 }
 

@@ -289,6 +289,19 @@ def stft_db(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: int
     check(lib().jsg_stft_db_launch(plan._p, C.byref(a), C.c_void_p(stream)))
 
 
+def columns_from_tail_layout(d_db, d_tail, d_dst, *, stream: int | None = None):
+    """jsg_columns_from_tail_layout_launch: d_db [W][pitch >= n/2] + d_tail [W] (the tail-plane layout of stft_db(..., d_tail=)) -> d_dst [W][>= n/2+1],
+    the reference's dense column shape (what getMem hands out)."""
+    import torch
+    assert d_db.is_cuda and d_tail.is_cuda and d_dst.is_cuda and d_db.dim() == 2 and d_dst.dim() == 2 and d_db.stride(1) == 1 and d_dst.stride(1) == 1
+    W = d_db.shape[0]
+    assert d_tail.numel() == W and d_tail.is_contiguous() and d_dst.shape[0] == W
+    H = min(d_db.shape[1], d_dst.shape[1] - 1) + 1
+    if stream is None:
+        stream = torch.cuda.current_stream(d_db.device).cuda_stream
+    check(lib().jsg_columns_from_tail_layout_launch(d_db.data_ptr(), d_db.stride(0), d_tail.data_ptr(), W, H, d_dst.data_ptr(), d_dst.stride(0), C.c_void_p(stream)))
+
+
 def stft_db_batches(plan: Plan, batches, hop: int, n_frames: int, *, stream: int | None = None, **kw):
     """jsg_stft_db_launch_batches: `batches` = [(d_in, d_out), ...] independent launches of the same geometry, stream-ordered with
     respect to `stream` like one launch but overlapped on the library's own working streams (include/jsg.h)."""

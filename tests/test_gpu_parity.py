@@ -432,6 +432,23 @@ def test_seeded_random_geometries(jsg, oracle, torch_cuda, n, channels, mix, fee
     peak = p64.max(axis=(0, 2))[:, None]                                  # largest per-channel peak of every frame
     assert_db_close(got[cols, :H], oracle.to_db(pw), pw.astype(np.float64),
                     f"n={n} C={channels} mix={mix} fb={feedblocks} hop={hop} F={frames}", peak=peak)
+    # round 5, on the same case: the tail-plane layout holds the very same values (every second case), and where the pair plan applies
+    # (2048 points, AbsMean over an even channel count) its columns hold the bound too
+    if (frames + channels) % 2 == 0:
+        d_dense = torch.full((W, n // 2), 7.0, device="cuda")
+        d_tail = torch.full((1, W), 7.0, device="cuda")
+        jsg.stft_db(plan, torch.from_numpy(x).cuda(), hop, frames, d_dense, feedblocks=feedblocks, mix_mode=mix, ring_pos=pos,
+                    plan_select=sel, d_tail=d_tail)
+        torch.cuda.synchronize()
+        assert torch.equal(d_dense, d_out[:, :n // 2]) and torch.equal(d_tail[0, cols], d_out[cols, n // 2]), "tail-plane layout differs"
+        assert bool((d_tail[0, np.setdiff1d(np.arange(W), cols)] == 7.0).all())
+    if n == 2048 and mix == 0 and channels % 2 == 0:
+        d_pair = torch.full((W, H + 2), 7.0, device="cuda")
+        jsg.stft_db(plan, torch.from_numpy(x).cuda(), hop, frames, d_pair, feedblocks=feedblocks, mix_mode=mix, ring_pos=pos, plan_select=3)
+        torch.cuda.synchronize()
+        gp = d_pair.cpu().numpy()
+        assert (gp[np.setdiff1d(np.arange(W), cols)] == 7.0).all() and (gp[:, H:] == 7.0).all()
+        assert_db_close(gp[cols, :H], oracle.to_db(pw), pw.astype(np.float64), f"pair plan C={channels} fb={feedblocks} hop={hop} F={frames}", peak=peak)
 
 
 def test_empty_inputs_and_bad_geometry(jsg, oracle, torch_cuda):

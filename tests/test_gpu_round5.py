@@ -306,3 +306,23 @@ def test_pair_plan_strided_batches_equal_single_launches(jsg, oracle, torch_cuda
         jsg.stft_db(plan, d_in[0], hop, F, lay, **kw)                       # the reference layout holds the same values
         torch.cuda.synchronize()
         assert torch.equal(lay[:, :M], ref[0]) and torch.equal(lay[cols, M], t_ref[0, 0, cols])
+
+
+def test_columns_from_tail_layout_gives_the_reference_shape(jsg, oracle, torch_cuda):
+    """jsg_columns_from_tail_layout_launch: whole-line columns + the plane of bin n/2 -> the dense [W][n/2+1] columns getMem hands out
+    (m_mem[col][bin], Spectrogram.h:144), equal to a launch in the reference layout."""
+    torch = torch_cuda
+    n, hop, F, W, pos = 1024, 512, 300, 320, 310
+    plan = jsg.Plan(n, oracle.window(oracle.WIN_HANN, n))
+    d_x = _rand_in(torch, (2, (F - 1) * hop + n), seed=77)
+    ref = torch.full((W, 544), -120.0, device="cuda")
+    dense = torch.full((W, 512), -120.0, device="cuda")
+    tail = torch.full((1, W), -120.0, device="cuda")
+    jsg.stft_db(plan, d_x, hop, F, ref, ring_pos=pos)
+    jsg.stft_db(plan, d_x, hop, F, dense, d_tail=tail, ring_pos=pos)
+    got = torch.full((W, 513), 3.0, device="cuda")
+    jsg.columns_from_tail_layout(dense, tail[0], got)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref[:, :513])
+    with pytest.raises(jsg.capi.JsgError):      # a destination that cannot hold n/2 + 1 floats per column
+        jsg.capi.check(jsg.capi.lib().jsg_columns_from_tail_layout_launch(dense.data_ptr(), 512, tail.data_ptr(), W, 513, got.data_ptr(), 512, None))

@@ -24,6 +24,12 @@ kw = dict(feedblocks=n // hop, mix_mode=jsg.capi.MIX_ABSMEAN)
 algo = (4 * hop * C + 4 * H) * F
 cfgs = [("reference layout (pitch %d, bin n/2 inline)" % pitch, lambda: jsg.stft_db_strided(plan, d_in, hop, F, ref, stream=st.cuda_stream, **kw)),
         ("tail plane (pitch %d + dense plane)" % M, lambda: jsg.stft_db_strided(plan, d_in, hop, F, dense, d_tail=tail, stream=st.cuda_stream, **kw))]
+for bpc in [int(v) for v in os.environ.get("TP_BPC", "").split(",") if v]:      # workgroups per CU of the grid, tail-plane layout
+    cfgs.append(("tail plane, %d workgroups per CU" % bpc,
+                 (lambda bpc: lambda: jsg.stft_db_strided(plan, d_in, hop, F, dense, d_tail=tail, blocks_per_cu=bpc, stream=st.cuda_stream, **kw))(bpc)))
+for bpc in [int(v) for v in os.environ.get("TP_BPC_REF", "").split(",") if v]:  # ... and the reference layout
+    cfgs.append(("reference layout, %d workgroups per CU" % bpc,
+                 (lambda bpc: lambda: jsg.stft_db_strided(plan, d_in, hop, F, ref, blocks_per_cu=bpc, stream=st.cuda_stream, **kw))(bpc)))
 with torch.cuda.stream(st):
     for _, fn in cfgs:
         fn()
