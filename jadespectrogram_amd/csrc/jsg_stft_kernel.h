@@ -687,7 +687,12 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     const unsigned xcd = b & 7, jb = b >> 3, full = nblk & ~255u;
     unsigned lb = b;
     if (a.xcd_remap) {
-        if (b < full) lb = ((jb >> 5) << 8) + (xcd << 5) + (jb & 31u);
+#ifndef JSG_X_XCD_CHUNK_LOG2
+#define JSG_X_XCD_CHUNK_LOG2 5   // (variant builds sweep this: tools/README.md)
+#endif
+        constexpr unsigned CL = JSG_X_XCD_CHUNK_LOG2;   // chunks of 2^CL workgroups per XCD; a "row" of eight chunks = 8 << CL logical blocks
+        if (b < full && b < (nblk & ~((8u << CL) - 1u))) lb = ((jb >> CL) << (CL + 3)) + (xcd << CL) + (jb & ((1u << CL) - 1u));
+        else if (b < full) lb = b;   // (between the last whole row of chunks and the last whole 256: identity)
         else {
             const unsigned t = nblk - full, q = t >> 3, r = t & 7;   // (full is a multiple of 8: block b - full sits on XCD b & 7 too)
             lb = full + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ((b - full) >> 3);

@@ -12,6 +12,7 @@ n = 2048; hop = int(os.environ.get("PP_HOP", "512")); C = int(os.environ.get("PP
 F = int(os.environ.get("PP_FRAMES", "4096")); K = int(os.environ.get("PP_BATCHES", "12"))
 reps = int(os.environ.get("PP_REPS", "8")); rounds = int(os.environ.get("PP_ROUNDS", "9"))
 plans = [int(v) for v in os.environ.get("PP_PLANS", "2,3").split(",")]
+bpcs = [int(v) for v in os.environ.get("PP_BPC", "0").split(",")]          # workgroups per CU of the grid (0: the library's default)
 use_tail = bool(os.environ.get("PP_TAIL"))
 M, H = n // 2, n // 2 + 1
 pitch = M if use_tail else 1056
@@ -25,7 +26,9 @@ st = torch.cuda.Stream()
 kw = dict(feedblocks=n // hop, mix_mode=jsg.capi.MIX_ABSMEAN)
 algo = (4 * hop * C + 4 * H) * F
 names = {p: jsg.stft_db_strided_kernel_name(plan, d_in, hop, F, outs[p], plan_select=p, d_tail=tails[p], **kw) for p in plans}
-fns = {p: (lambda p=p: jsg.stft_db_strided(plan, d_in, hop, F, outs[p], plan_select=p, d_tail=tails[p], stream=st.cuda_stream, **kw)) for p in plans}
+plans = [(p, b) for p in plans for b in bpcs]
+outs = {pb: outs[pb[0]] for pb in plans}; tails = {pb: tails[pb[0]] for pb in plans}; names = {pb: names[pb[0]] for pb in plans}
+fns = {pb: (lambda pb=pb: jsg.stft_db_strided(plan, d_in, hop, F, outs[pb], plan_select=pb[0], blocks_per_cu=pb[1], d_tail=tails[pb], stream=st.cuda_stream, **kw)) for pb in plans}
 with torch.cuda.stream(st):
     for p in plans:
         fns[p]()
@@ -46,6 +49,6 @@ base = outs[plans[0]][..., :M].double()
 for p in plans:
     t = sorted(times[p]); med = t[len(t) // 2]
     dev = float((outs[p][..., :M].double() - base).abs().max())
-    print(json.dumps({"plan_select": p, "kernel": names[p], "us_per_dispatch_median": round(med, 1), "best": round(t[0], 1), "fft_per_s_median": round(K * F * C / med * 1e6),
+    print(json.dumps({"plan_select": p[0], "blocks_per_cu": p[1], "kernel": names[p], "us_per_dispatch_median": round(med, 1), "best": round(t[0], 1), "fft_per_s_median": round(K * F * C / med * 1e6),
                       "frac_of_8_median": round(K * algo / med / 8e6, 4), "max_abs_dB_difference_to_first_plan": dev, "rounds": [round(x, 1) for x in times[p]]}))
 print(json.dumps({"channels": C, "hop": hop, "frames": F, "batches": K, "tail_plane": use_tail}))

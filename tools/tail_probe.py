@@ -6,6 +6,8 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import jadespectrogram_amd as jsg
+if os.environ.get("SP_LIB"):          # a variant build (python -m jadespectrogram_amd._build --variant NAME ...)
+    jsg.capi.LIB_PATH = os.path.abspath(os.environ["SP_LIB"])
 
 n = int(os.environ.get("TP_N", "1024")); hop = int(os.environ.get("TP_HOP", "512")); C = int(os.environ.get("TP_CHANNELS", "1"))
 F = int(os.environ.get("TP_FRAMES", "4096")); K = int(os.environ.get("TP_BATCHES", "64"))
