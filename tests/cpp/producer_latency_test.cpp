@@ -106,6 +106,34 @@ int main(int argc, char** argv) {
         getrusage(RUSAGE_THREAD, &ru);
         return ru.ru_nivcsw;
     };
+    // ... and a CONTROL on the same thread, same core, same moment: right after every real call the same number of bytes is copied into an
+    // ordinary private buffer and one atomic is touched -- no library, no page-locked memory, no other thread -- and timed the same way.  A
+    // tail that the control shows too belongs to the box (interrupt handlers and hypervisor time are charged to whatever thread is running
+    // and are NOT context switches), not to jsg_process_block.
+    std::vector<float> ctrl_dst(size_t(C) * N);
+    std::atomic<unsigned long long> ctrl_word{0};
+    size_t ctrl_over50 = 0, ctrl_cpu_over50 = 0;
+    double ctrl_max = 0.0;
+    // interrupts served by the producer's CPU during the run (/proc/interrupts, the column of that CPU)
+    auto irqs_on_cpu = [](int cpu) -> long long {
+        FILE* f = std::fopen("/proc/interrupts", "r");
+        if (!f) return -1;
+        long long total = 0;
+        char line[16384];
+        if (!std::fgets(line, sizeof line, f)) { std::fclose(f); return -1; }      // header: CPU0 CPU1 ...
+        int col = -1, k = 0;
+        for (char* tok = std::strtok(line, " \t\n"); tok; tok = std::strtok(nullptr, " \t\n"), ++k)
+            if (std::strncmp(tok, "CPU", 3) == 0 && std::atoi(tok + 3) == cpu) col = k;
+        while (col >= 0 && std::fgets(line, sizeof line, f)) {
+            char* tok = std::strtok(line, " \t\n");                                 // "NN:" label
+            for (int c = 0; tok && c <= col; ++c) tok = std::strtok(nullptr, " \t\n");
+            if (tok && tok[0] >= '0' && tok[0] <= '9') total += std::atoll(tok);
+        }
+        std::fclose(f);
+        return total;
+    };
+    const int my_cpu = sched_getcpu();
+    const long long irq_before = irqs_on_cpu(my_cpu);
     std::vector<double> lat, cpu;
     std::vector<unsigned char> switched;
     lat.reserve(size_t(blocks));
@@ -125,9 +153,26 @@ int main(int argc, char** argv) {
         lat.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
         cpu.push_back(c1 - c0);
         switched.push_back(sw1 != sw0);
+        {   // the control: the same bytes into private memory, timed the same way
+            const double k0 = thread_cpu_us();
+            const auto u0 = std::chrono::steady_clock::now();
+            ctrl_word.fetch_add(1);
+            for (int c = 0; c < C; ++c) std::memcpy(ctrl_dst.data() + size_t(c) * N, ptrs[c], size_t(N) * sizeof(float));
+            ctrl_word.fetch_add(1);
+            const auto u1 = std::chrono::steady_clock::now();
+            const double k1 = thread_cpu_us();
+            const double w = std::chrono::duration<double, std::micro>(u1 - u0).count();
+            if (b > 0) {
+                ctrl_over50 += w > 50.0;
+                ctrl_cpu_over50 += (k1 - k0) > 50.0;
+                ctrl_max = std::max(ctrl_max, w);
+            }
+        }
         if (pace_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(pace_us));
     }
     const long nivcsw_total = nivcsw() - nivcsw_before;
+    const long long irq_after = irqs_on_cpu(my_cpu);
+    if (ctrl_dst[7] == 12345.678f) std::fprintf(stderr, "(keep the control copy)\n");
     // long calls (wall clock > 50 us): how many coincide with an involuntary switch, how many are long in thread-CPU time as well
     size_t long_calls = 0, long_with_switch = 0, long_cpu_over_50 = 0, cpu_over_50 = 0;
     double cpu_max = 0.0, cpu_max_of_long = 0.0;
@@ -180,10 +225,13 @@ int main(int argc, char** argv) {
                 "\"pos_live\": %d, \"pos_batch\": %d, \"differing_floats\": %zu, \"differing_pixels\": %zu, "
                 "\"thread_cpu_p50_us\": %.2f, \"thread_cpu_p9999_us\": %.2f, \"thread_cpu_max_after_first_us\": %.1f, \"thread_cpu_calls_over_50us\": %zu, "
                 "\"long_wall_calls_after_first\": %zu, \"long_wall_calls_with_involuntary_switch\": %zu, \"long_wall_calls_long_in_thread_cpu_too\": %zu, "
-                "\"thread_cpu_max_of_long_wall_calls_us\": %.1f, \"involuntary_switches_total\": %ld}\n",
+                "\"thread_cpu_max_of_long_wall_calls_us\": %.1f, \"involuntary_switches_total\": %ld, "
+                "\"control_copy_calls_over_50us\": %zu, \"control_copy_thread_cpu_over_50us\": %zu, \"control_copy_max_us\": %.1f, "
+                "\"producer_cpu\": %d, \"interrupts_on_producer_cpu_during_run\": %lld}\n",
                 blocks, W, H, reads.load(), pct(0.5), pct(0.99), pct(0.9999), lat.back(), first_us, max_after_first, worst_at, over50, dropped, pa, pr, diff_floats, diff_px,
                 cpu_sorted[size_t(0.5 * double(cpu_sorted.size() - 1))], cpu_sorted[size_t(0.9999 * double(cpu_sorted.size() - 1))], cpu_max, cpu_over_50,
-                long_calls, long_with_switch, long_cpu_over_50, cpu_max_of_long, nivcsw_total);
+                long_calls, long_with_switch, long_cpu_over_50, cpu_max_of_long, nivcsw_total,
+                ctrl_over50, ctrl_cpu_over50, ctrl_max, my_cpu, (irq_before >= 0 && irq_after >= 0) ? irq_after - irq_before : -1LL);
     jsg_destroy(live);
     jsg_destroy(batch);
     return 0;
