@@ -415,7 +415,8 @@ def colormap(d_db, d_lut, lo: float, hi: float, *, d_argb=None, d_index=None, co
 
 def _stft_image_args(plan: Plan, d_in, hop: int, n_frames: int, d_lut, lo: float, hi: float, d_argb, d_index_scratch, *,
                      feedblocks: int | None = None, mix_mode: int = 0, first_frame: int = 0, ring_pos: int = 0,
-                     ring_width: int | None = None, x_first: int | None = None, plan_select: int = 0, exact_log: bool = False):
+                     ring_width: int | None = None, x_first: int | None = None, plan_select: int = 0, exact_log: bool = False,
+                     blocks_per_cu: int = 0):
     import torch
     assert d_argb.is_cuda and d_argb.element_size() == 4 and d_argb.dim() == 2 and d_argb.stride(1) == 1
     if d_index_scratch is not None:
@@ -437,6 +438,7 @@ def _stft_image_args(plan: Plan, d_in, hop: int, n_frames: int, d_lut, lo: float
     st.ring_pos = ring_pos
     st.plan_select = int(plan_select)
     st.exact_log = int(bool(exact_log))
+    st.blocks_per_cu = int(blocks_per_cu)
     a.stft = st
     c = capi.ColormapArgs()
     c.ring_width = W
