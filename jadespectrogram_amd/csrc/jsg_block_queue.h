@@ -69,10 +69,16 @@ struct BlockQueue {
         return rc > 0 ? 1 : rc;
     }
     // would a push of this geometry be taken right now?  (single producer: free slots can only grow until its next push)
-    bool can_push(int ch_check, int n_check) const {
-        if ((cfg_gen.load() & 1u) || !mem || channels <= 0 || n <= 0) return false;
-        if ((ch_check > 0 && ch_check != channels) || (n_check > 0 && n_check != n)) return false;
-        return head.load(std::memory_order_relaxed) - tail.load(std::memory_order_acquire) < (unsigned long long)kSlots;
+    // (the same hand-shake as try_push: the geometry fields may only be read between inflight++ and inflight-- with an even cfg_gen seen in
+    // between -- the setter waits for inflight == 0 behind making cfg_gen odd; ThreadSanitizer found the unprotected first version)
+    bool can_push(int ch_check, int n_check) {
+        inflight.fetch_add(1);
+        bool ok = false;
+        if (!(cfg_gen.load() & 1u) && mem && channels > 0 && n > 0 &&
+            !((ch_check > 0 && ch_check != channels) || (n_check > 0 && n_check != n)))
+            ok = head.load(std::memory_order_relaxed) - tail.load(std::memory_order_acquire) < (unsigned long long)kSlots;
+        inflight.fetch_sub(1);
+        return ok;
     }
 
     // consumer: the oldest block, if any (`current`: it was pushed under the geometry that is in force)
