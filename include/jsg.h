@@ -154,7 +154,11 @@ typedef struct jsg_stft_args {
                                 kernel otherwise.  1: always the small-workgroup kernel, 2: always "B".  The two round differently in
                                 the last bits (both inside the parity bound): callers that cut one stream into launches of
                                 very different sizes and need bit-identical columns pin one of them (the engine pins 1).
-                                jsg_stft_kernel_name() tells which one a launch takes.  Other sizes: ignored */
+                                jsg_stft_kernel_name() tells which one a launch takes.  3 (2048 points, round 5): the PAIR plan "Cfg2048P"
+                                where it applies -- AbsMean / Sum over an even channel count, dB / power launches: two channels as one
+                                complex transform z = x_c + i x_(c+1), sum |X_c|^2 = (|Z[k]|^2 + |Z[N-k]|^2) / 2 (a reassociation of the
+                                mix of Spectrogram.cpp:64-76 inside the parity bound); as 0 where it does not.  Never chosen
+                                automatically: on an MI355X it is slower than "B" (DESIGN.md section 6).  Other sizes: ignored */
     int32_t exact_log;       /* 0: 10*log10 on the hardware log unit (1 ulp, not specified bit for bit); 1: by the library's own float32
                                 routine (jadespectrogram_amd/csrc/jsg_exact_math.h: exponent + degree-9 polynomial, within 2 ulp of the
                                 reference's double log10): every dB value -- and so every palette index and ARGB pixel -- is then
