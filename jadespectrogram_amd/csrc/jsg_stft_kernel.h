@@ -622,11 +622,7 @@ __device__ __forceinline__ cf mix_combine2(cf acc, cf pw) {
 // wave for the whole iteration, and that wave then idles at the workgroup barrier of the store phase (in-kernel stamps, tools/abbench
 // AB_IMGSTAMPS: the median wave waited there for 20 % of a one-image launch, 7 % with the marks; C5 image in order 21.4 vs 22.0 us,
 // 30 000 columns in one launch 226 vs 235 us; the strided batches of the bench are level, 14.3 us per image either way).
-#ifdef JSG_X_MARK_ALL   // (variant builds: the progress marks in every output form)
-#define JSG_MARK(k) do { __builtin_amdgcn_s_setprio(3 - ((k) & 3)); } while (0)
-#else
 #define JSG_MARK(k) do { if constexpr (OUTK == 2) __builtin_amdgcn_s_setprio(3 - ((k) & 3)); } while (0)
-#endif
 // STREAM (jsg_stft_db_launch_strided: K independent batches of one geometry in ONE launch, OUTK == 0): 0 = one batch per launch;
 // 1 = the workgroups walk through the groups (TPB consecutive columns) of all batches, everything else as for one batch: tables loaded
 // once per workgroup and launch, the prefetch pipeline alive across batches, no ramp-up and drain per 4096 frames.
