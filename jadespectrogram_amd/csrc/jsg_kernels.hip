@@ -392,6 +392,7 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
         ka.top = io->vmax * 0.9999f;
         ka.mult = io->mult;
         ka.n_colors = io->n_colors;
+        ka.cmap_fast = jsg::cmap_is_fast(ka.vmin, ka.vmax, ka.top, ka.mult, ka.n_colors) ? 1 : 0;
     }
     static const int xcd_remap = dev_knob_set("JSG_NO_XCD_REMAP") ? 0 : 1;   // (variant builds only, as every dev_knob_*)
     ka.xcd_remap = xcd_remap;

@@ -215,6 +215,28 @@ __device__ __forceinline__ void dft_win(cf (&x)[R], const cf (&w)[R / 2]) {
     }
 }
 
+// everything of dft_win<R> behind the sums and differences of its first layer (a[J], d[J] as DifLayerWin forms them): natural order out
+template <int R, int J>
+struct DifTwiddle {
+    static __device__ __forceinline__ void run(const cf (&d)[R / 2], cf (&b)[R / 2]) {
+        b[J] = mul_w_q1<J % (R / 4), R>(d[J]);
+        if constexpr (J + 1 < R / 2) DifTwiddle<R, J + 1>::run(d, b);
+    }
+};
+template <int R>
+__device__ __forceinline__ void dft_rest(cf (&a)[R / 2], const cf (&d)[R / 2], cf (&x)[R]) {
+    static_assert(R >= 4, "radix");
+    cf b[R / 2];
+    DifTwiddle<R, 0>::run(d, b);
+    dft<R / 2, false>(a);
+    dft<R / 2, true>(b);
+#pragma unroll
+    for (int q = 0; q < R / 2; ++q) {
+        x[2 * q] = a[q];
+        x[2 * q + 1] = b[q];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Split-radix register DFTs for R = 16 and 32 (round 5).  The radix-2 recursion above spends 10 (R = 16) / 34
 // (R = 32) non-trivial twiddle multiplies per transform, the split-radix one 8 / 26: X[2k] comes from the half-size transform of
@@ -382,9 +404,13 @@ __device__ __forceinline__ cf to_cf(const f2u& v) { return cf{v.x, v.y}; }
 //   transform the even and the odd samples (E, O: two N/2-point FFTs with the two-stage engine of Cfg2048B), a v_permlane32_swap brings
 //   E[k] and O[k] into one lane, and Z[k] = E[k] + W_N^k O[k], Z[k + N/2] = E[k] - W_N^k O[k].  See "pair plan" in the kernel.
 template <int N_, int R1_, int R2_, int R3_, int L_, int S1_, int AX_, int AY_, int AZ_, int WPB_, int TLOC_, int WPS_,
-          int FPW_ = 1, int RESERVED_ = 0, int TWF_ = 0, int PAIR_ = 0>
+          int FPW_ = 1, int EARLY1_ = 0, int TWF_ = 0, int PAIR_ = 0>
 struct Cfg {
     static constexpr bool PAIR = PAIR_ != 0;
+    // EARLY1 (round 5): the first butterfly layer of stage 1 -- the one that carries the window -- runs AHEAD of the next round's frame loads.
+    // It consumes every raw sample, so the loads land in the registers they leave; otherwise the raw lower inputs outlive the loads and the
+    // compiler copies them out of the way first (Cfg4096B: 32 v_mov per FFT round in the ISA).  Same operations, same bits.
+    static constexpr bool EARLY1 = EARLY1_ != 0;
     // TWF: factorised twiddle tables (for plans whose full lane tables do not fit beside the exchange buffers).  The stage-2
     // twiddle W_M^(n3 (k1 + R1 k2)) is read as B[n3][k2] = W_(M/R1)^(n3 k2) (one row per n3, shared by the lanes) times the
     // lane's constant A[v] = W_M^(n3 k1); the post-pass twiddle -i W_N^(ll + L rho) as the lane's constant C = -i W_N^ll times
@@ -453,7 +479,7 @@ using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 4, 1, 6>;
 using Cfg1024I = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 6>;
 // factorised stage-2 / post tables (Cfg::TWF): 11.3 instead of 21.2 KB of tables, so that THREE 4-wave workgroups fit a CU (12 waves
 // instead of 8): stereo launches -9..-13 %, mono -1..-5 %
-using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 1, 3, 1, 0, 1>;   // (6-, 8-, 12-wave workgroups: no faster)
+using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 1, 3, 1, 1, 1>;   // (6-, 8-, 12-wave workgroups: no faster)
 // 2048 points as TWO radix-32 stages with ONE exchange: 32 lanes per frame, 32 complex values per lane, two frames side by side
 // in a wavefront.  Against the three-stage plan (16*8*8, 64 lanes): the same butterfly count, but 40 % fewer LDS
 // instructions per frame (one exchange of 16 + 16 instead of two of 32 + 32), which is what capped C3 (VALU and LDS
@@ -484,14 +510,14 @@ constexpr int k4096B_min_channels = 1;   // ... the one-wavefront-per-frame 4096
 // stream that fall on different sides of that rule therefore agree within the float32 bound, not bit for bit; everything
 // with one or two channels per column, and the engine's per-block launches, always take the small-workgroup plan.
 constexpr double kB_min_round_fill = 0.87;
-using Cfg4096 = Cfg<4096, 16, 8, 16, 128, 144, 1, 272, 17, 4, 1, 1>;
+using Cfg4096 = Cfg<4096, 16, 8, 16, 128, 144, 1, 272, 17, 4, 1, 1, 1, 1>;
 // 4096 points with ONE wavefront per frame: 8*16*16, 32 complex values per lane, both exchanges wave-private (no workgroup
 // barrier at all), one 8-wave workgroup per CU.  8 x 17.6 KB of exchange leave 22 KB of LDS for tables, so only the window
 // and the stage-1 rows are kept whole and the other two tables are factorised (Cfg::TWF: one more complex multiply per
 // value).  Like Cfg2048B it trades waves per SIMD for independence of the waves: measured (abbench --cfg x4096, 16 384 FFTs,
 // us three-stage two-wave plan -> this one) 8 ch 56.4 -> 48.4, 4 ch 57.2 -> 52.5, 2 ch 59.4 -> 60.6 (61.4 -> 67.4 at 50 %
 // overlap), 1 ch 66.4 -> 79.1: it is the plan of the launches that mix >= 3 channels into a column.
-using Cfg4096B = Cfg<4096, 8, 16, 16, 64, 272, 276, 17, 1, 8, 1, 1, 1, 0, 1>;    // two wavefronts per frame, two frames per workgroup
+using Cfg4096B = Cfg<4096, 8, 16, 16, 64, 272, 276, 17, 1, 8, 1, 1, 1, 1, 1>;    // two wavefronts per frame, two frames per workgroup
 // four wavefronts per frame, one frame per workgroup.  Its full lane tables (82 KB) do not fit beside the exchange buffer,
 // and reading them from L2 at every use cost 12 %: the factorised set (Cfg::TWF, 40.7 KB) lives in LDS like everywhere else.
 using Cfg8192 = Cfg<8192, 16, 16, 16, 256, 272, 1, 272, 17, 4, 1, 1, 1, 0, 1>;
@@ -525,6 +551,7 @@ struct StftKArgs {
     long long idx_pitch;          // bytes between index columns
     float vmin, vmax, top, mult;  // CColorPalette::setValueRange / getRGBColor (CColorpalette.cpp:39-54, CColorpalette.h:34-45)
     int n_colors;
+    int cmap_fast;                // 1: for this range the index is min(u32((v - vmin) * mult), n_colors - 1) for EVERY v (see color_index2_fast)
     // OUTK == 2 (single-kernel display path): the workgroup turns the columns of an iteration into ARGB image rows itself
     unsigned* argb;               // image [height][argb_pitch], pixel (x, height - 1 - bin)
     long long argb_pitch;
@@ -574,6 +601,38 @@ __device__ __forceinline__ void color_index2(cf v, float vmin, float vmax, float
     iy = (int)t.y;
     ix = ix < n_colors ? ix : n_colors - 1;
     iy = iy < n_colors ? iy : n_colors - 1;
+}
+
+// The same index without the two selects, for value ranges where they cannot matter (round 5; the launcher decides: cmap_is_fast).  The
+// reference replaces v >= max by max * 0.9999 and v < min by min before it scales.  The lower clamp is what v_cvt_u32_f32 does to a negative
+// product (it saturates at 0; NaN gives 0 too, as above).  The upper replacement is visible only if the index of max * 0.9999 is NOT the
+// last colour -- for the plugin's ranges it is (-50 .. +50 dB, 256 colours: 255.987 -> 255) -- or if a value between max and max * 0.9999
+// (a negative max) could land below it; with mult > 0 the scaling is monotone, so checking those two indices on the host covers every v.
+// 5 instead of 12 instructions per pair: the display kernels spend them on every bin.
+__device__ __forceinline__ void color_index2_fast(cf v, float vmin, float mult, int n_colors, int& ix, int& iy) {
+    const cf t = (v - cf{vmin, vmin}) * cf{mult, mult};
+    unsigned ux, uy;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(ux) : "v"(t.x));
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(uy) : "v"(t.y));
+    const unsigned last = (unsigned)(n_colors - 1);
+    ix = (int)(ux < last ? ux : last);
+    iy = (int)(uy < last ? uy : last);
+}
+// host side of the above: true if color_index2_fast equals color_index for every float v of this range (float32 arithmetic as on the device)
+inline bool cmap_is_fast(float vmin, float vmax, float top, float mult, int n_colors) {
+    if (!(mult > 0.0f) || !(vmax > vmin) || n_colors < 1) return false;
+    auto raw = [&](float v) -> long long {   // u32((v - vmin) * mult), saturating like v_cvt_u32_f32
+        volatile float d = v - vmin;
+        volatile float t = d * mult;
+        const float tt = t;
+        if (!(tt > 0.0f)) return 0;
+        return tt >= 4294967296.0f ? 4294967295ll : (long long)tt;
+    };
+    const long long last = n_colors - 1;
+    // v >= vmax is replaced by top (then clamped from below): its index must be the last colour, and so must the unreplaced one of every
+    // v >= vmax (the smallest is vmax itself; monotone from there)
+    const float topc = top < vmin ? vmin : top;
+    return raw(topc) >= last && raw(vmax) >= last;
 }
 
 template <int MIXOP>
@@ -937,6 +996,20 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
         // pair plan: the first butterfly layer of stage 1 runs HERE, ahead of the prefetch: it consumes every raw value, so the loads below
         // can land in the registers they leave.  (Left to the scheduler, the raw lower inputs -- which the other plans' register allocation
         // keeps through the prefetch for free -- were copied first: 38 v_mov per round in the ISA.)
+        // EARLY1: sums and differences of the first layer for every butterfly of the lane, register m = u + U1 J (J < R1 / 2), ahead of the loads
+        cf fa[C::EARLY1 ? F : 1][C::EARLY1 ? P / 2 : 1], fd[C::EARLY1 ? F : 1][C::EARLY1 ? P / 2 : 1];
+        if constexpr (C::EARLY1) {
+            static_assert(!C::EARLY1 || !C::PAIR, "the pair plan has its own early first layer");
+#pragma unroll
+            for (int f = 0; f < F; ++f)
+#pragma unroll
+                for (int m = 0; m < P / 2; ++m) {
+                    const cf hi = x[f][m + P / 2];
+                    fa[f][m] = __builtin_elementwise_fma(x[f][m], wlo[m], hi);
+                    fd[f][m] = __builtin_elementwise_fma(x[f][m], wlo[m], -hi);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         cf pa[C::PAIR ? R1 / 2 : 1], pb[C::PAIR ? R1 / 2 : 1];
         if constexpr (C::PAIR) {
             static_assert(!C::PAIR || U1 == 1, "pair plan: one radix-R1 butterfly per lane");
@@ -984,6 +1057,15 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                         t[f][2 * q] = pa[q];
                         t[f][2 * q + 1] = pb[q];
                     }
+                } else if constexpr (C::EARLY1) {
+                    cf ea[R1 / 2], ed[R1 / 2];
+#pragma unroll
+                    for (int J = 0; J < R1 / 2; ++J) {
+                        ea[J] = fa[f][u + U1 * J];
+                        ed[J] = fd[f][u + U1 * J];
+                    }
+                    if constexpr (R1 <= 8) dft_rest<R1>(ea, ed, t[f]);
+                    else sr_rest<R1>(ea, ed, t[f]);
                 } else {
                 cf wl[R1 / 2];
 #pragma unroll
@@ -1261,6 +1343,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
             for (int f = 0; f < F; ++f) {
                 unsigned col = a.ring_pos + task_of(it, f);        // n_frames <= ring_w (checked by the launcher)
                 if (col >= (unsigned)a.ring_w) col -= a.ring_w;
+                const bool fuse_scale = !ONE && !XLOG && !a.linear && !a.exact_div;   // (uniform) v_log path of a mixing kernel: see below
                 if constexpr (ONE) {
                     // one channel: the launcher selects this instantiation only when the mix scale is exactly 1
                 } else
@@ -1268,7 +1351,7 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
 #pragma unroll
                     for (int m = 0; m < P / 2; ++m) acc[f][m] = cf{acc[f][m].x / a.divisor, acc[f][m].y / a.divisor};
                     accNy[f] = accNy[f] / a.divisor;
-                } else if (a.scale != 1.0f) {   // power-of-two channel count: the same division as an exact scaling
+                } else if (a.scale != 1.0f && !fuse_scale) {   // power-of-two channel count: the same division as an exact scaling
 #pragma unroll
                     for (int m = 0; m < P / 2; ++m) acc[f][m] *= a.scale;
                     accNy[f] *= a.scale;
@@ -1279,13 +1362,19 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                         for (int m = 0; m < P / 2; ++m) acc[f][m] = cf{jsg_exact_db(acc[f][m].x), jsg_exact_db(acc[f][m].y)};
                         accNy[f] = jsg_exact_db(accNy[f]);
                     } else {
+                    // (mixing kernels: the exact scaling by 1 / channels rides on the floor add as one packed fma -- the product is exact, so
+                    // fma(p, 1/C, 1e-11) == p / C + 1e-11 bit for bit, and with 1/C == 1 it IS the add; one packed multiply less per pair)
+                    const float sc = fuse_scale ? a.scale : 1.0f;
 #pragma unroll
                     for (int m = 0; m < P / 2; ++m) {   // to_db() of both values of a pair: packed add and multiply around the two v_log
-                        cf t = acc[f][m] + cf{1e-11f, 1e-11f};
+                        cf t;
+                        if constexpr (ONE) t = acc[f][m] + cf{1e-11f, 1e-11f};
+                        else t = __builtin_elementwise_fma(acc[f][m], cf{sc, sc}, cf{1e-11f, 1e-11f});
                         t = cf{__builtin_amdgcn_logf(t.x), __builtin_amdgcn_logf(t.y)};
                         acc[f][m] = t * cf{3.0102999566398120f, 3.0102999566398120f};
                     }
-                    accNy[f] = to_db(accNy[f]);
+                    if constexpr (ONE) accNy[f] = to_db(accNy[f]);
+                    else accNy[f] = __builtin_amdgcn_logf(__builtin_fmaf(accNy[f], sc, 1e-11f)) * 3.0102999566398120f;
                     }
                 }
                 if constexpr (L == 32) {
@@ -1315,19 +1404,25 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                     constexpr int D = C::LDS_ELEMS * 2;                       // dwords between the waves' regions
                     constexpr int SK = ((4 - D % 32) + 32) % 32;              // skew per wave: (D + SK) == 4 (mod 32)
                     unsigned* ix = reinterpret_cast<unsigned*>(lds0 + f * C::LDS_ELEMS) + (SK * wave) % 32;
+                    auto park = [&](auto fast_tag) {
+                        constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
-                    for (int r4 = 0; r4 < P / 8; ++r4) {
-                        unsigned wx = 0, wy = 0;
+                        for (int r4 = 0; r4 < P / 8; ++r4) {
+                            unsigned wx = 0, wy = 0;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            int ix_, iy_;
-                            color_index2(acc[f][4 * r4 + j], a.vmin, a.vmax, a.top, a.mult, a.n_colors, ix_, iy_);
-                            wx |= (unsigned)ix_ << (8 * j);
-                            wy |= (unsigned)iy_ << (8 * j);
+                            for (int j = 0; j < 4; ++j) {
+                                int ix_, iy_;
+                                if constexpr (FAST) color_index2_fast(acc[f][4 * r4 + j], a.vmin, a.mult, a.n_colors, ix_, iy_);
+                                else color_index2(acc[f][4 * r4 + j], a.vmin, a.vmax, a.top, a.mult, a.n_colors, ix_, iy_);
+                                wx |= (unsigned)ix_ << (8 * j);
+                                wy |= (unsigned)iy_ << (8 * j);
+                            }
+                            ix[r4 * 64 + ll] = wx;
+                            ix[(P / 8 + r4) * 64 + ll] = wy;
                         }
-                        ix[r4 * 64 + ll] = wx;
-                        ix[(P / 8 + r4) * 64 + ll] = wy;
-                    }
+                    };
+                    if (a.cmap_fast) park(std::true_type{});   // (uniform)
+                    else park(std::false_type{});
                     if (ll == 0) ix[(P / 4) * 64] = (unsigned)color_index(accNy[f], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
                     __syncthreads();
                     {
@@ -1368,19 +1463,26 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                         // whole lines, streamed out (non-temporal) every piece went to memory alone: 28.6 vs 22.3 us per C5 image
                         unsigned oLo = ((unsigned)M - k0) * pitch4 + x * 4u, oUp = k0 * pitch4 + x * 4u;
                         if (live) {
+                            // All palette reads of the lane first, then the stores (round 5).  Written pixel by pixel the compiler issued read,
+                            // s_waitcnt lgkmcnt(0), store -- 33 LDS round trips in a row per wave, at the one moment when both waves of
+                            // a SIMD are in this phase and cannot cover for each other.  The FFT's registers are dead here: 33 more cost nothing.
+                            unsigned rgb[NI * 4];
+#pragma unroll
+                            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) rgb[4 * i + j] = (unsigned)s_lut[(w4[i] >> (8 * j)) & 0xffu];
+                            const unsigned rgbNy = (unsigned)s_lut[wNy & 0xffu];
+                            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                             for (int i = 0; i < NI; ++i) {
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
-                                    const unsigned rgb = (unsigned)s_lut[(w4[i] >> (8 * j)) & 0xffu];
-                                    if (i < P / 8) { *reinterpret_cast<unsigned*>(img + oLo) = rgb; oLo -= step; }
-                                    else { *reinterpret_cast<unsigned*>(img + oUp) = rgb; oUp += step; }
+                                    if (i < P / 8) { *reinterpret_cast<unsigned*>(img + oLo) = rgb[4 * i + j]; oLo -= step; }
+                                    else { *reinterpret_cast<unsigned*>(img + oUp) = rgb[4 * i + j]; oUp += step; }
                                 }
                             }
-                            if (wave == C::WPB - 1 && dl == 0) {     // (row M - M / 2)
-                                const unsigned rgb = (unsigned)s_lut[wNy & 0xffu];
-                                *reinterpret_cast<unsigned*>(img + ((unsigned)(M / 2) * pitch4 + x * 4u)) = rgb;
-                            }
+                            if (wave == C::WPB - 1 && dl == 0)     // (row M - M / 2)
+                                *reinterpret_cast<unsigned*>(img + ((unsigned)(M / 2) * pitch4 + x * 4u)) = rgbNy;
                         }
                     }
                 } else if constexpr (OUTK == 1) {
@@ -1394,15 +1496,21 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                     // handful of integer adds.
                     int lwo = lw;
                     asm volatile("" : "+v"(lwo));
+                    auto put = [&](auto fast_tag) {
+                        constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
-                    for (int rho = 0; rho < P / 2; ++rho) {
-                        unsigned char* d = (L == 32 && (rho & 1)) ? icB : icA;
-                        const int k = lwo + LW * (L == 32 ? rho / 2 : rho);
-                        int ix_, iy_;
-                        color_index2(acc[f][rho], a.vmin, a.vmax, a.top, a.mult, a.n_colors, ix_, iy_);
-                        d[k] = (unsigned char)ix_;
-                        d[M - k] = (unsigned char)iy_;
-                    }
+                        for (int rho = 0; rho < P / 2; ++rho) {
+                            unsigned char* d = (L == 32 && (rho & 1)) ? icB : icA;
+                            const int k = lwo + LW * (L == 32 ? rho / 2 : rho);
+                            int ix_, iy_;
+                            if constexpr (FAST) color_index2_fast(acc[f][rho], a.vmin, a.mult, a.n_colors, ix_, iy_);
+                            else color_index2(acc[f][rho], a.vmin, a.vmax, a.top, a.mult, a.n_colors, ix_, iy_);
+                            d[k] = (unsigned char)ix_;
+                            d[M - k] = (unsigned char)iy_;
+                        }
+                    };
+                    if (a.cmap_fast) put(std::true_type{});   // (uniform)
+                    else put(std::false_type{});
                     if (L <= 64 || ll == 0) ic[M / 2] = (unsigned char)color_index(accNy[f], a.vmin, a.vmax, a.top, a.mult, a.n_colors);
                 } else {
                     // non-temporal dword stores, 256 contiguous bytes of the column per instruction (streaming the columns out
@@ -1475,7 +1583,11 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                     }
                 }
 #pragma unroll
-                for (int m = 0; m < P / 2; ++m) acc[f][m] = cf{init, init};
+                for (int m = 0; m < P / 2; ++m) {
+                    // (sum mix: one 64-bit move per pair, written out -- the compiler zeroes the pairs with two 32-bit moves each)
+                    if constexpr (MIXOP == 0) asm volatile("v_mov_b64 %0, 0" : "=v"(acc[f][m]));
+                    else acc[f][m] = cf{init, init};
+                }
                 accNy[f] = init;
             }
         }

@@ -326,3 +326,43 @@ def test_columns_from_tail_layout_gives_the_reference_shape(jsg, oracle, torch_c
     assert torch.equal(got, ref[:, :513])
     with pytest.raises(jsg.capi.JsgError):      # a destination that cannot hold n/2 + 1 floats per column
         jsg.capi.check(jsg.capi.lib().jsg_columns_from_tail_layout_launch(dense.data_ptr(), 512, tail.data_ptr(), W, 513, got.data_ptr(), 512, None))
+
+
+# ---- round 5: the palette index without the two selects, where the value range allows it (color_index2_fast / cmap_is_fast) ----
+# The launcher decides per range; the image must be that of the dB columns + the colour kernel (which keeps the reference's form, selects
+# included) bit for bit either way.  Ranges: the plugin's default (fast), a negative maximum (max * 0.9999 lies ABOVE max), a range whose
+# replaced value does not reach the last colour (narrow range far from zero: the selects are needed), an inverted range, a range the
+# signal saturates on both sides, few colours.
+@pytest.mark.parametrize("lo,hi,n_colors", [(-50.0, 50.0, 256), (-120.0, -10.0, 256), (999.0, 1000.0, 256), (-30.0, -29.5, 256), (20.0, -80.0, 256),
+                                            (-70.0, -35.0, 256), (-50.0, 50.0, 7), (-0.001, 0.001, 256), (-90.0, 0.0, 64)])
+@pytest.mark.parametrize("n,C,F,one_kernel", [(4096, 2, 1875, True), (1024, 1, 2048, True), (2048, 2, 600, False), (4096, 2, 300, False)])
+def test_display_launch_equals_db_plus_colour_kernel_for_every_value_range(jsg, oracle, torch_cuda, lo, hi, n_colors, n, C, F, one_kernel):
+    torch = torch_cuda
+    hop = n // 8
+    H = n // 2 + 1
+    plan = jsg.Plan(n, oracle.window(oracle.WIN_HANN, n))
+    # a signal whose dB values cross the whole range: a tone on noise, the level swept over 140 dB along the stream
+    ns = (F - 1) * hop + n
+    t = np.arange(ns, dtype=np.float64)
+    rng = np.random.default_rng(n + C + F)
+    x = np.stack([(np.sin(2 * np.pi * (0.01 + 0.07 * c) * t) + 0.3 * rng.standard_normal(ns)) * 10.0 ** (-7.0 + 7.5 * t / ns) for c in range(C)]).astype(np.float32)
+    d_in = torch.from_numpy(x).cuda()
+    d_lut = torch.from_numpy(jsg.colormap_lut(n_colors, jsg.capi.CM_JADE)).cuda()
+    pitch = (F + 31) // 32 * 32
+    W = (H + 31) // 32 * 32
+    d_db = torch.empty((F, W), device="cuda")
+    two = torch.zeros((H, pitch), dtype=torch.int32, device="cuda")
+    fused = torch.zeros_like(two)
+    scratch = torch.zeros((F, W), dtype=torch.uint8, device="cuda")
+    kw = dict(feedblocks=8, mix_mode=jsg.capi.MIX_ABSMEAN)
+    jsg.stft_db(plan, d_in, hop, F, d_db, **kw)
+    jsg.colormap(d_db, d_lut, lo, hi, d_argb=two[:, :F], col_first=0, x_first=0, height=H)
+    needs = jsg.stft_image_needs_scratch(plan, d_in, hop, F, d_lut, lo, hi, fused[:, :F], scratch, **kw)
+    assert needs == (not one_kernel)
+    jsg.stft_image(plan, d_in, hop, F, d_lut, lo, hi, fused[:, :F], scratch, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(fused, two), f"{int((fused != two).sum())} pixels differ"
+    if not one_kernel:   # the index scratch of the two-kernel form: the oracle's palette index of the GPU's own dB values
+        pal = oracle.OracleColorPalette(n_colors, oracle.CM_JADE)
+        pal.set_value_range(lo, hi)
+        assert (scratch[:, :H].cpu().numpy() == pal.index(d_db[:, :H].cpu().numpy()).astype(np.uint8)).all()

@@ -5,6 +5,8 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import jadespectrogram_amd as jsg
+if os.environ.get("SP_LIB"):
+    jsg.capi.LIB_PATH = os.path.abspath(os.environ["SP_LIB"])
 n, hop, C, F, K = 4096, 512, 2, 1875, int(os.environ.get("C5_IMAGES", "44"))
 H = n // 2 + 1
 pitch = (F + 31) // 32 * 32
