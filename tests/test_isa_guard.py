@@ -142,3 +142,27 @@ def test_no_fused_lds_pairs_in_the_stft_kernels(tmp_path):
             continue
         fused = [ins for ins in body if ins.startswith(("ds_read2", "ds_write2"))]
         assert not fused, f"{name}: {len(fused)} fused LDS pair instructions, e.g. {fused[0]}"
+
+
+def test_early_first_layer_leaves_no_register_copies_in_front_of_the_frame_loads(tmp_path):
+    """Cfg::EARLY1 (round 5): the first butterfly layer runs ahead of the next round's frame loads, so the loads land in the registers the raw
+    samples leave.  Without it the compiler copied the raw lower inputs out of the way -- 32 v_mov per FFT round in Cfg4096B's loop.  The guard:
+    in the 60 instructions in front of every burst of frame loads of an EARLY1 instantiation there are at most four VGPR-to-VGPR moves."""
+    text = _disassemble(tmp_path)
+    checked = 0
+    for name, body in _functions(text):
+        if "stft_db_kernel" not in name:
+            continue
+        m = re.search(r"3CfgI((?:Li\d+E)+)E", name)
+        vals = [int(v) for v in re.findall(r"Li(\d+)E", m.group(1))]
+        if len(vals) < 14 or vals[13] != 1:      # Cfg<..., FPW, EARLY1, TWF, PAIR>
+            continue
+        loads = [i for i, ins in enumerate(body) if ins.startswith("global_load_dwordx2") or ins.startswith("global_load_dword ")]
+        bursts = [i for k, i in enumerate(loads) if k == 0 or i - loads[k - 1] > 40]
+        assert bursts, name
+        for b in bursts:
+            window = body[max(0, b - 60):b]
+            copies = [ins for ins in window if re.match(r"v_mov_b32_e32 v\d+, v\d+$", ins) or re.match(r"v_mov_b64_e32 v\[\d+:\d+\], v\[\d+:\d+\]$", ins)]
+            assert len(copies) <= 4, f"{name}: {len(copies)} register copies in front of the frame loads at instruction {b}"
+        checked += 1
+    assert checked >= 30   # Cfg2048, Cfg4096, Cfg4096B in all their output forms
