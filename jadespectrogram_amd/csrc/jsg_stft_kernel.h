@@ -1339,6 +1339,16 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
             }
         } else
         if (ONE || s - (int)it * nc == nc - 1) {
+            // The eight waves of a "B" workgroup run independently (no barrier in the FFT), and over the 100 and more rounds of a persistent
+            // workgroup they drift apart by whole columns: a wave then fetches the samples it shares with its neighbours (3/4 of a frame at 75 %
+            // overlap) long after those have left the L2 -- the C3 dispatch read 1.38 x its samples from memory (round 4-5 counters).  With >= 4
+            // channels per column the waves therefore meet at a column end about every 8 FFT rounds (round 5; C3: every column): reads 1.38 ->
+            // 0.98 x (1.21 x with a period of 16), C3 +1..2 %, 8 channels at 4096 points +4..5 %.  With one or two channels per column the
+            // meeting costs more than the traffic (stereo at 4096 points -4 % with a period of 4 or 8 rounds, level with 16; mono -1..-3 %):
+            // not done there.  Every wave of the workgroup runs the same rounds, so the condition is uniform.
+            if constexpr ((C::TWO_STAGE || (C::N == 4096 && L == 64)) && OUTK != 2 && !C::PAIR && !ONE) {
+                if (nc >= 4 && (unsigned)(s + 1) / 8u != (unsigned)(s + 1 - nc) / 8u) __syncthreads();
+            }
 #pragma unroll
             for (int f = 0; f < F; ++f) {
                 unsigned col = a.ring_pos + task_of(it, f);        // n_frames <= ring_w (checked by the launcher)
