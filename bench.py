@@ -173,7 +173,7 @@ def cpu_baseline(c, seconds_budget: float = 10.0):
 # derived) and the shader clock the chip holds under that load (C3: SQ_WAVE_CYCLES x 4 / waves = 67.7 k cycles per wave over a
 # 40.4 us dispatch = 1.68 GHz -- well under the 2.4 GHz maximum: packed-math kernels are power-limited): the issue roof of the
 # compute-bound configurations (a wave64 VALU instruction holds its SIMD for 4 cycles; 256 CUs x 4 SIMDs).
-VALU_PER_FFT = {"c2": 180.0, "c3": 352.0, "c5": 1084.0}   # round 5: split-radix 16- and 32-point stages (366 and 1099 before)
+VALU_PER_FFT = {"c2": 188.0, "c3": 352.0, "c5": 989.0}   # round 5: split-radix 16- and 32-point stages, the display kernel's trims (366 and 1099 before)
 CLOCK_GHZ_UNDER_LOAD = 1.7
 
 
