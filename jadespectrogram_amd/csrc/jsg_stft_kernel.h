@@ -404,9 +404,14 @@ __device__ __forceinline__ cf to_cf(const f2u& v) { return cf{v.x, v.y}; }
 //   transform the even and the odd samples (E, O: two N/2-point FFTs with the two-stage engine of Cfg2048B), a v_permlane32_swap brings
 //   E[k] and O[k] into one lane, and Z[k] = E[k] + W_N^k O[k], Z[k + N/2] = E[k] - W_N^k O[k].  See "pair plan" in the kernel.
 template <int N_, int R1_, int R2_, int R3_, int L_, int S1_, int AX_, int AY_, int AZ_, int WPB_, int TLOC_, int WPS_,
-          int FPW_ = 1, int EARLY1_ = 0, int TWF_ = 0, int PAIR_ = 0>
+          int FPW_ = 1, int EARLY1_ = 0, int TWF_ = 0, int PAIR_ = 0, int RTAB_ = 0>
 struct Cfg {
     static constexpr bool PAIR = PAIR_ != 0;
+    // RTAB (round 5): the one-channel dB kernels of the plan keep their stage-1 and post-pass twiddles (R1 - 1 + P/2 complex values per lane) in
+    // registers for the whole kernel instead of reading them from the LDS tables in every FFT round.  A timing experiment with ALL lane-table
+    // reads removed put their cost at 3-4 % of the C2 dispatch (5-7 % at C3, where no register is free); Cfg1024's one-channel kernel has 66 of
+    // the 96 VGPRs that five waves per SIMD -- all its LDS allows -- may use: 6 of its 14 table reads per frame go, 86 VGPRs, +3..5 %.
+    static constexpr bool RTAB = RTAB_ != 0;
     // EARLY1 (round 5): the first butterfly layer of stage 1 -- the one that carries the window -- runs AHEAD of the next round's frame loads.
     // It consumes every raw sample, so the loads land in the registers they leave; otherwise the raw lower inputs outlive the loads and the
     // compiler copies them out of the way first (Cfg4096B: 32 v_mov per FFT round in the ISA).  Same operations, same bits.
@@ -473,7 +478,7 @@ using Cfg512 = Cfg<512, 8, 8, 4, 32, 36, 4, 33, 1, 8, 1, 2>;   // (a 80-VGPR bud
 // builds of the same source -- the C2 dispatch +2.3..+2.7 % on five boxes (0.582-0.585 -> 0.594-0.601 of 8 TB/s) and -1.9 % on one
 // (0.648 -> 0.636), the C4 shard (8 channels, one column each) +5.9 %, 75 % overlap +11 %, single launches of <= 1024 frames +14 %, two
 // channels mixed level, eight channels mixed -3.5 %.  Workgroups of 2 waves: +1 %; of 3, 5, 6 waves: -4..-5 %.
-using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 4, 1, 6>;
+using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 4, 1, 6, 1, 0, 0, 0, 1>;   // (RTAB: the one-channel dB kernels hold two of the four tables in registers)
 // ... and the eight-wave form for the single-kernel display path (OUTK == 2), whose store phase is laid out for eight columns per step;
 // same tables, same arithmetic per frame (bit-identical columns); instantiated for that path only (image_only)
 using Cfg1024I = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 6>;
@@ -696,7 +701,9 @@ __device__ __forceinline__ cf mix_combine2(cf acc, cf pw) {
 // the default path does not know it exists.  Round 4 ran it as a second elementwise pass over the columns of a launch (one more read and
 // write of the output, and no display path); since round 5 it sits in the epilogue of every output form.
 template <class C, int MIXOP, int OUTK = 0, int STREAM = 0, int XLOG = 0>
-__global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_kernel(
+// (RTAB instantiations: five waves per SIMD -- what the plan's LDS allows -- instead of the plan's C::WPS, see Cfg::RTAB)
+#define JSG_RTAB_OF(C, MIXOP, OUTK) (C::RTAB && MIXOP == 3 && OUTK == 0)
+__global__ __launch_bounds__(C::WPB * 64, (JSG_RTAB_OF(C, MIXOP, OUTK) ? 5 : C::WPS)) JSG_NO_LDS_MERGE void stft_db_kernel(
     // Everything the table and frame loads depend on sits in the first 16 dwords of the kernel arguments: with
     // -amdgpu-kernarg-preload-count=16 those arrive in SGPRs with the wave, so the loads are issued without waiting for a
     // scalar-memory round trip to the kernarg segment (4096 waves starting at once queue up on the scalar cache:
@@ -909,6 +916,24 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
     int tw1row[U1];                                   // row of this lane's butterfly u in the stage-1 table
 #pragma unroll
     for (int u = 0; u < U1; ++u) tw1row[u] = ((ll + L * u) / R3) * C::TS1;
+    // RTAB: stage-1 row and post-pass twiddles of this lane, read once (the tables are in LDS behind the barrier above)
+    constexpr bool RTAB = JSG_RTAB_OF(C, MIXOP, OUTK);
+    cf rt1[RTAB ? R1 : 1], rpost[RTAB ? P / 2 : 1];
+    if constexpr (RTAB) {
+        static_assert(!RTAB || (U1 == 1 && !C::TWF && !C::PAIR && C::TLOC == 1), "register tables: one stage-1 butterfly per lane, whole tables in LDS");
+#pragma unroll
+        for (int k1 = 1; k1 < R1; k1 += 2) {
+            const v4f q4 = *reinterpret_cast<const v4f*>(tTw1 + tw1row[0] + k1 - 1);
+            rt1[k1] = cf{q4.x, q4.y};
+            if (k1 + 1 < R1) rt1[k1 + 1] = cf{q4.z, q4.w};
+        }
+#pragma unroll
+        for (int rho = 0; rho < P / 2; rho += 2) {
+            const v4f q4 = *reinterpret_cast<const v4f*>(tBase + C::TAB_POST + C::tab_idx(rho, tl));
+            rpost[rho] = cf{q4.x, q4.y};
+            rpost[rho + 1] = cf{q4.z, q4.w};
+        }
+    }
     // values j and j + 1 (j even) of this lane from the [J][TL] table at `off`: one 16-byte read (pair layout)
     auto tab2 = [&](int off, int j, cf& a0, cf& a1) {
         const v4f q4 = *reinterpret_cast<const v4f*>(tBase + off + C::tab_idx(j, tl));
@@ -1076,7 +1101,9 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
             }
 #pragma unroll
             for (int k1 = 1; k1 < R1; k1 += 2) {   // row: k1 = 1, 2 | 3, 4 | ... | R1 - 1, (pad)
-                const v4f q4 = *reinterpret_cast<const v4f*>(tTw1 + tw1row[u] + k1 - 1);
+                v4f q4;
+                if constexpr (RTAB) q4 = v4f{rt1[k1].x, rt1[k1].y, rt1[k1 + 1 < R1 ? k1 + 1 : k1].x, rt1[k1 + 1 < R1 ? k1 + 1 : k1].y};
+                else q4 = *reinterpret_cast<const v4f*>(tTw1 + tw1row[u] + k1 - 1);
 #pragma unroll
                 for (int f = 0; f < F; ++f) {
                     lds0[f * C::LDS_ELEMS + k1 * C::S1 + ll + L * u] = cmul(t[f][k1], cf{q4.x, q4.y});
@@ -1244,7 +1271,8 @@ __global__ __launch_bounds__(C::WPB * 64, C::WPS) JSG_NO_LDS_MERGE void stft_db_
                     constexpr int Q = 64 / (C::N / L);   // W_(N/L)^rho as a multiple of 2 pi / 64
                     wpost[rho] = cmul_s(twC, cf{kCos64[Q * rho], -kSin64[Q * rho]});
                     wpost[rho + 1] = cmul_s(twC, cf{kCos64[Q * (rho + 1)], -kSin64[Q * (rho + 1)]});
-                } else tab2(C::TAB_POST, rho, wpost[rho], wpost[rho + 1]);
+                } else if constexpr (RTAB) { wpost[rho] = rpost[rho]; wpost[rho + 1] = rpost[rho + 1]; }
+                else tab2(C::TAB_POST, rho, wpost[rho], wpost[rho + 1]);
             }
 #pragma unroll
             for (int f = 0; f < F; ++f) {

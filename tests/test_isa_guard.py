@@ -57,7 +57,7 @@ def test_counted_wait_matches_the_emitted_frame_loads(tmp_path):
     for name, body in _functions(text):
         if "stft_db_kernel" not in name and "stft_image_kernel" not in name:
             continue
-        # Cfg<N, R1, R2, R3, L, S1, AX, AY, AZ, WPB, TLOC, WPS, FPW, HX, TWF, PAIR>
+        # Cfg<N, R1, R2, R3, L, S1, AX, AY, AZ, WPB, TLOC, WPS, FPW, EARLY1, TWF, PAIR, RTAB>
         m = re.search(r"3CfgI((?:Li\d+E)+)E", name)
         vals = [int(v) for v in re.findall(r"Li(\d+)E", m.group(1))]
         n, lanes, tloc, fpw = vals[0], vals[4], vals[10], vals[12]
