@@ -166,3 +166,34 @@ def test_early_first_layer_leaves_no_register_copies_in_front_of_the_frame_loads
             assert len(copies) <= 4, f"{name}: {len(copies)} register copies in front of the frame loads at instruction {b}"
         checked += 1
     assert checked >= 30   # Cfg2048, Cfg4096, Cfg4096B in all their output forms
+
+
+def test_register_resident_twiddles_keep_five_waves_per_simd(tmp_path):
+    """Cfg::RTAB (round 5): the one-channel 1024-point dB kernels hold two lane tables in registers.  Their LDS allows five waves per SIMD, i.e.
+    96 VGPRs: the guard reads the register count of those instantiations from the code object's metadata (and that nothing spills)."""
+    for tool in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf"):
+        if not os.path.exists(os.path.join(LLVM, tool)):
+            pytest.skip(f"{tool} not found under {LLVM}")
+    if not os.path.exists(OBJS[0]):
+        from jadespectrogram_amd import _build
+        _build.build_lib()
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", OBJS[0], str(tmp_path / "scratch.o")])
+    subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                           f"--input={fat}", f"--output={co}"])
+    notes = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co]).decode()
+    checked = 0
+    for blk in re.split(r"\n\s+- \.agpr_count", notes)[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        m = re.search(r"stft_db_kernelINS_3CfgI((?:Li\d+E)+)EELi(\d)ELi(\d)ELi(\d)ELi(\d)E", name)
+        if not m:
+            continue
+        vals = [int(v) for v in re.findall(r"Li(\d+)E", m.group(1))]
+        mixop, outk = int(m.group(2)), int(m.group(3))
+        if not (len(vals) >= 17 and vals[16] == 1 and mixop == 3 and outk == 0):   # Cfg<..., PAIR, RTAB>, one channel per column, dB / power out
+            continue
+        vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
+        spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1))
+        assert vgpr <= 96 and spill == 0, f"{name}: {vgpr} VGPRs, {spill} spilled"
+        checked += 1
+    assert checked == 4   # single / strided x v_log / exact log
