@@ -701,8 +701,10 @@ __device__ __forceinline__ cf mix_combine2(cf acc, cf pw) {
 // the default path does not know it exists.  Round 4 ran it as a second elementwise pass over the columns of a launch (one more read and
 // write of the output, and no display path); since round 5 it sits in the epilogue of every output form.
 template <class C, int MIXOP, int OUTK = 0, int STREAM = 0, int XLOG = 0>
-// (RTAB instantiations: five waves per SIMD -- what the plan's LDS allows -- instead of the plan's C::WPS, see Cfg::RTAB)
-#define JSG_RTAB_OF(C, MIXOP, OUTK) (C::RTAB && MIXOP == 3 && OUTK == 0)
+// (RTAB instantiations: five waves per SIMD -- what the plan's LDS allows -- instead of the plan's C::WPS, see Cfg::RTAB.  Strided dispatches
+// only: a single launch of one 4096-frame batch gives every wave ONE frame, and reading the tables into registers first costs it 1-1.5 %
+// -- 5.33 vs 5.25 us, tools/single_launch_probe.py.)
+#define JSG_RTAB_OF(C, MIXOP, OUTK) (C::RTAB && MIXOP == 3 && OUTK == 0 && STREAM == 1)
 __global__ __launch_bounds__(C::WPB * 64, (JSG_RTAB_OF(C, MIXOP, OUTK) ? 5 : C::WPS)) JSG_NO_LDS_MERGE void stft_db_kernel(
     // Everything the table and frame loads depend on sits in the first 16 dwords of the kernel arguments: with
     // -amdgpu-kernarg-preload-count=16 those arrive in SGPRs with the wave, so the loads are issued without waiting for a

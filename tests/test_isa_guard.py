@@ -190,10 +190,10 @@ def test_register_resident_twiddles_keep_five_waves_per_simd(tmp_path):
             continue
         vals = [int(v) for v in re.findall(r"Li(\d+)E", m.group(1))]
         mixop, outk = int(m.group(2)), int(m.group(3))
-        if not (len(vals) >= 17 and vals[16] == 1 and mixop == 3 and outk == 0):   # Cfg<..., PAIR, RTAB>, one channel per column, dB / power out
+        if not (len(vals) >= 17 and vals[16] == 1 and mixop == 3 and outk == 0 and int(m.group(4)) == 1):   # Cfg<..., PAIR, RTAB>, one channel per column, dB / power out, strided
             continue
         vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
         spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1))
         assert vgpr <= 96 and spill == 0, f"{name}: {vgpr} VGPRs, {spill} spilled"
         checked += 1
-    assert checked == 4   # single / strided x v_log / exact log
+    assert checked == 2   # strided dispatches: v_log / exact log (single launches keep the LDS reads: one frame per wave)

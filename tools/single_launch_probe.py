@@ -2,6 +2,8 @@ import json, os, sys
 sys.path.insert(0, "/root/repo")
 import torch
 import jadespectrogram_amd as jsg
+if os.environ.get("SP_LIB"):
+    jsg.capi.LIB_PATH = os.path.abspath(os.environ["SP_LIB"])
 n, hop, F, K = 1024, 512, 4096, 64
 plan = jsg.Plan(n, jsg.window(jsg.capi.WIN_HANN, n))
 ns = F * hop + n - hop
