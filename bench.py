@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
 """Headline benchmark: STFT frames/sec (1024-pt, 50 % hop) on N MI355X, with the kernel's HBM roofline fraction.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by torch.distributed.run with one
-rank per GPU.  Rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it through torch.distributed.run with one
+rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE in the environment).  Started WITHOUT a launcher (`python bench.py --gpus 8`), the parent
+process -- before it imports torch or touches a GPU -- starts the N ranks itself (spawn_ranks) and exits with their code.  Rank 0 prints ONE
+JSON line.
 
 What a step is
 --------------
 A step is a FIXED, stated number of kernel dispatches over synthetic batches that are resident in HBM, all on ONE stream, in
 order, issued by plain C calls -- no extra streams, no hardware-queue setting, no issuing threads, no hipGraph:
 
-  c2 (default, BASELINE.json configs[1]: mono 48 kHz, 1024-point FFT, hop 512, Hann, batches of 4096 frames): one step =
+  c2 (default at N = 1, BASELINE.json configs[1]: mono 48 kHz, 1024-point FFT, hop 512, Hann, batches of 4096 frames): one step =
       16 dispatches of jsg_stft_db_launch_strided, each covering the whole rotation of 64 independent 4096-frame batches
       (64 x 4096 frames per dispatch) = 4 194 304 frames per step.  The workgroups of a dispatch walk through the batches.
+      The columns are written in the REFERENCE's layout m_mem[col][bin] (Spectrogram.h:144: n/2+1 contiguous floats per column); the
+      tail-plane layout of jsg_stft_args.out_tail is timed beside it (roofline.frac_tail_plane), as is the literal one batch per
+      dispatch (roofline.frac_one_batch_per_dispatch).
+  c4 (default at N > 1, configs[3]: 64 channels sharded 8 per GPU): every rank holds 8 channels and writes one dB column PER CHANNEL
+      (JSG_MIX_PER_CHANNEL; the reference's channel loop Spectrogram.cpp:52-59 without the mix of :64-76); one step = 10 dispatches x
+      12 batches x 8 channels x 4096 frames; 4100 algorithmic bytes per channel-frame.  The N = 1 line carries one GPU's shard as extra.c4.
   c3 (configs[2]: 8 channels, 2048 points, 75 % overlap, AbsMean): one step = 4 dispatches x 12 batches x 4096 columns.
   c5 (configs[4]: stereo 96 kHz, 4096 points, 87.5 % overlap -> ARGB): one step = 3 dispatches of jsg_stft_image_launch_strided,
       each a whole rotation of ~44 independent 1875-column images.
@@ -31,8 +39,8 @@ the same kernel sources.  `calibration` = what a tuned float4 copy (jsg_calib_co
 sampled from its hwmon files: every kernel of this path runs the socket into its 1400 W cap, the core clock gives.
 
 Every rank works on its own batches (weak scaling; the path shards by channel / stream, there is no data-path collective); RCCL
-carries only the barriers and the max-over-ranks time.  At N = 1 the default line also carries the c3 and c5 results (`extra`), from
-child processes that run BEFORE this process touches the GPU.
+carries only the barriers and the max-over-ranks time.  At N = 1 the default line also carries the c4, c3 and c5 results (`extra`, and as
+scalars roofline.extra_<cfg>_frac / _value), from child processes that run BEFORE this process touches the GPU.
 """
 from __future__ import annotations
 
@@ -47,6 +55,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PROFILE_ROUND = "r06"        # profiles/<round>_<cfg>_hbm_traffic.json: the rocprofv3 passes this build's figures are compared with
 ROTATION_BYTES = 1.0e9       # distinct input + output bytes the timed launches rotate over (>> 256 MiB Infinity Cache)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_GUIDE_COPY_GBS = 6290.0  # ... and 6.29 TB/s for a float4 copy in the guide; bench.py measures its own (calibrate_copy)
@@ -60,6 +69,12 @@ CONFIGS = {
     "c3": dict(n=2048, hop=512, channels=8, frames=4096, fs=48000.0, colour=False, dispatches_per_step=4, batches_per_dispatch=12,
                metric="STFT frames/sec (2048-pt, 75% overlap, 8 channels mixed to one column)", unit="frames/s",
                workload="configs[2]: 8-channel 48 kHz, 2048-pt FFT, 512 hop (75 % overlap), Hann, AbsMean mix, 4096 columns/launch"),
+    # configs[3]: the shard ONE GPU holds of the 64-channel stream (8 channels per GPU at N = 8), one column PER CHANNEL (the reference's channel loop,
+    # Spectrogram.cpp:52-59, without the mix of :64-76 -- channels are independent up to there): rows = batch x channel of a strided dispatch
+    "c4": dict(n=1024, hop=512, channels=8, frames=4096, fs=48000.0, colour=False, per_channel=True, dispatches_per_step=10, batches_per_dispatch=12,
+               metric="STFT frames/sec (1024-pt, 50% hop)", unit="frames/s",
+               workload="configs[3]: 64-channel synthetic 48 kHz, 1024-pt FFT, 512 hop, Hann, sharded 8 channels per GPU (this GPU's shard: 8 channels, "
+                        "one dB column per channel and frame, JSG_MIX_PER_CHANNEL), batches of 4096 frames per channel, no data-path collective"),
     "c5": dict(n=4096, hop=512, channels=2, frames=1875, fs=96000.0, colour=True, dispatches_per_step=3, batches_per_dispatch=44,
                metric="STFT->ARGB columns/sec (4096-pt, 87.5% overlap, stereo 96 kHz)", unit="columns/s",
                workload="configs[4]: stereo 96 kHz, 4096-pt FFT, 512 hop (87.5 % overlap), AbsMean, Jade LUT -50..50 dB -> ARGB image, "
@@ -69,18 +84,22 @@ CONFIGS = {
 
 def algorithmic_bytes_per_batch(c) -> int:
     H = c["n"] // 2 + 1
+    if c.get("per_channel"):                                                       # every channel-frame: its hop of input + its own dB column (4100 B at 1024 / 512)
+        return (4 * c["hop"] + 4 * H) * c["channels"] * c["frames"]
     per_column = 4 * c["hop"] * c["channels"] + (4 * H if c["colour"] else 4 * H)   # input once + one dB column, or one ARGB column
     return per_column * c["frames"]
 
 
-def synth_audio(channels: int, n_samples: int, fs: float = 48000.0, seed: int = 1234):
-    """SURVEY 8d synthetic input: x_c[n] = 0.5 sin(2 pi f_c n / fs) + 0.1 u[n], f_c = 220*2^(c/12), u ~ U(-1,1)."""
+def synth_audio(channels: int, n_samples: int, fs: float = 48000.0, seed: int = 1234, first_channel: int = 0):
+    """SURVEY 8d synthetic input: x_c[n] = 0.5 sin(2 pi f_c n / fs) + 0.1 u[n], f_c = 220*2^(c/12), u ~ U(-1,1); c counts from
+    `first_channel` (a rank's shard of a wider stream)."""
     import numpy as np
     out = np.zeros((channels, n_samples), dtype=np.float32)
     t = np.arange(n_samples, dtype=np.float64)
     for c in range(channels):
-        u = np.random.default_rng(seed + c).uniform(-1.0, 1.0, n_samples)
-        out[c] = (0.5 * np.sin(2.0 * np.pi * 220.0 * 2.0 ** (c / 12.0) * t / fs) + 0.1 * u).astype(np.float32)
+        g = first_channel + c
+        u = np.random.default_rng(seed + g).uniform(-1.0, 1.0, n_samples)
+        out[c] = (0.5 * np.sin(2.0 * np.pi * 220.0 * 2.0 ** (g / 12.0) * t / fs) + 0.1 * u).astype(np.float32)
     return out
 
 
@@ -141,7 +160,11 @@ def cpu_baseline(c, seconds_budget: float = 10.0):
         lut = oracle.compute_colors(256, oracle.CM_JADE)
 
     def once(threads):
-        port.stft_db(x, n, hop, cols, win, feedblocks=fb, mix=0, threads=threads, out=out)
+        if c.get("per_channel"):                      # one column per channel: the channels are independent mono streams
+            for ch in range(C):
+                port.stft_db(x[ch:ch + 1], n, hop, cols, win, feedblocks=fb, mix=0, threads=threads, out=out)
+        else:
+            port.stft_db(x, n, hop, cols, win, feedblocks=fb, mix=0, threads=threads, out=out)
         if c["colour"]:
             port.colour_columns(out, lut, float(pal.vmin), float(pal.vmax), float(pal.mult), threads=threads)
 
@@ -258,6 +281,8 @@ def parity_report(jsg, c, plan, d_in_host, win):
     n, hop, C = c["n"], c["hop"], c["channels"]
     H = n // 2 + 1
     F = c["frames"]                                   # the timed launch geometry
+    if c.get("per_channel"):
+        return parity_report_per_channel(jsg, c, plan, d_in_host, win)
     x = d_in_host[:, :(F - 1) * hop + n]
     d_x = torch.from_numpy(np.ascontiguousarray(x)).cuda()
     pitch = (H + 31) // 32 * 32
@@ -324,6 +349,52 @@ def parity_report(jsg, c, plan, d_in_host, win):
             "fused_image_pixels_differing_from_two_kernel_image": fused_differs,
             "exact_log_display_launch_vs_cpu_mirror": exact_flips,
             "note": "float64 DFT of the float32 windowed frames is the yardstick; indices: Jade, 256 colours, -50..50 dB"}
+
+
+def parity_report_per_channel(jsg, c, plan, d_in_host, win):
+    """parity_report for the per-channel workload (c4): one launch of the timed geometry (all channels, JSG_MIX_PER_CHANNEL), every channel's columns
+    against the float64 DFT of its own float32 windowed frames, and its palette indices end to end.  Checker code: oracle/ (test infrastructure)."""
+    import numpy as np
+    import torch
+    from oracle import jsg_oracle as oracle
+    n, hop, C, F = c["n"], c["hop"], c["channels"], c["frames"]
+    H = n // 2 + 1
+    x = d_in_host[:, :(F - 1) * hop + n]
+    d_x = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    pitch = (H + 31) // 32 * 32
+    mix = jsg.capi.MIX_PER_CHANNEL
+    d_pow = torch.empty((C, F, pitch), dtype=torch.float32, device="cuda")
+    d_db = torch.empty((C, F, pitch), dtype=torch.float32, device="cuda")
+    kernel = jsg.stft_kernel_name(plan, d_x, hop, F, d_pow, feedblocks=n // hop, mix_mode=mix)
+    jsg.stft_db(plan, d_x, hop, F, d_pow, feedblocks=n // hop, mix_mode=mix, linear_out=True)
+    jsg.stft_db(plan, d_x, hop, F, d_db, feedblocks=n // hop, mix_mode=mix)
+    torch.cuda.synchronize()
+    cols = np.unique(np.linspace(0, F - 1, min(F, 128)).astype(np.int64))
+    idx = (cols * hop)[:, None] + np.arange(n)[None, :]
+    frames = (x[:, idx] * win[None, None, :]).astype(np.float32)                       # [C][F'][n]
+    ref_p = oracle.power_spectrum_f64(frames).astype(np.float32).astype(np.float64)   # [C][F'][H]
+    got_p = d_pow[:, :, :H].cpu().numpy()[:, cols].astype(np.float64)
+    rel = np.abs(got_p - ref_p) / np.maximum(ref_p, 1e-300)
+    bad = rel > 1e-5
+    peak = ref_p.max(axis=2, keepdims=True)
+    level_db = 10.0 * np.log10(np.maximum(ref_p, 1e-300) / peak)
+    strong = ref_p > 1e-2 * peak
+    pal = oracle.OracleColorPalette(256, oracle.CM_JADE)
+    pal.set_value_range(-50.0, 50.0)
+    ref_db = oracle.to_db(ref_p.astype(np.float32))
+    got_db = d_db[:, :, :H].cpu().numpy()[:, cols]
+    flips = int((pal.index(got_db) != pal.index(ref_db)).sum())
+    return {"kernel": kernel, "launch_checked": f"{F} columns x {C} channels, one column per channel (the timed geometry, one batch)",
+            "columns_checked_against_float64": int(len(cols) * C), "bins_checked": int(rel.size),
+            "frac_bins_rel_power_err_gt_1e-5": float(bad.mean()),
+            "those_bins_level_below_frame_peak_db": {"median": float(np.median(level_db[bad])) if bad.any() else None,
+                                                     "highest": float(level_db[bad].max()) if bad.any() else None},
+            "max_rel_power_err_bins_within_20dB_of_peak": float(rel[strong].max()),
+            "max_err_relative_to_frame_peak": float((np.abs(got_p - ref_p) / peak).max()),
+            "max_abs_db_err": float(np.abs(got_db.astype(np.float64) - ref_db.astype(np.float64)).max()),
+            "colour_index_flips_end_to_end": flips, "pixels_checked": int(got_db.size),
+            "note": "float64 DFT of the float32 windowed frames is the yardstick; indices: GPU dB and oracle dB through the oracle's CColorPalette "
+                    "(Jade, 256 colours, -50..50 dB)"}
 
 
 def power_report(torch, lib, stream, run_step, units_per_step, bytes_per_step, seconds, dev_index):
@@ -426,20 +497,34 @@ def run_extra_config(cfg):
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
+def spawn_ranks(n: int, argv) -> int:
+    """Start `n` ranks of this script on this node (one per GPU) and return their exit code.  No torch import, no GPU call in this process."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                    help="default: c2 (BASELINE configs[1]) on one GPU, c4 (configs[3]: 8 channels per GPU, one column per channel) with --gpus N > 1")
     ap.add_argument("--dispatches-per-step", type=int, default=0, help="kernel dispatches in one step (default: the configuration's)")
     ap.add_argument("--nbuf", type=int, default=0, help="batches (c5: images) per dispatch = distinct batches rotated through (default: ~1 GB worth)")
     ap.add_argument("--mode", choices=("strided", "single"), default="strided",
                     help="strided: one dispatch covers all batches of the rotation (default); single: one dispatch per batch, in order")
     ap.add_argument("--blocks-per-cu", type=int, default=0, help="workgroups per CU of a dispatch (0: the library's choice)")
     ap.add_argument("--layout", choices=("auto", "tail", "reference"), default="auto",
-                    help="dB column layout of the timed dispatches: reference = bin n/2 inline (pitch n/2+1 rounded up to 32 floats); tail = "
-                         "jsg_stft_args.out_tail: columns of exactly n/2 floats + a dense plane of bin n/2 (same values; auto: tail for c2)")
+                    help="dB column layout of the timed dispatches: reference (= auto) = the reference's m_mem[col][bin]: bin n/2 inline, n/2+1 contiguous "
+                         "floats per column (pitch rounded up to 32 floats); tail = jsg_stft_args.out_tail: columns of exactly n/2 floats + a dense "
+                         "plane of bin n/2 (same values; the c2 line reports it as a side leg, roofline.frac_tail_plane)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the `parity` block (the profile scripts: its few launches would mix into the tracer's averages)")
     ap.add_argument("--no-boundary", action="store_true", help="skip the `boundary` block (jsg_process_block latency, PCIe-inclusive rate)")
@@ -452,6 +537,13 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="no GPU work at all: exercises the N-rank plumbing (barriers, reductions, "
                                                            "JSON) on a machine without GPUs; value is null")
     args = ap.parse_args()
+    if args.config is None:
+        args.config = "c2" if args.gpus <= 1 else "c4"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher around it: this parent -- which has not imported torch and never touches a GPU -- starts
+        # the N ranks as fresh processes (torch.distributed.run -> N x `bench.py --gpus N ...`), lets rank 0's JSON line through and exits with
+        # their code.  (Never an exec from a process that has initialised the GPU; the parent has not.)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     c = dict(CONFIGS[args.config])
     dps = args.dispatches_per_step or c["dispatches_per_step"]
 
@@ -467,7 +559,7 @@ def main():
         oracle_c.load()
     extra = None
     if not args.dry_run and not args.no_extra and world == 1 and not args.sub_run and args.config == "c2":
-        extra = {cfg: run_extra_config(cfg) for cfg in ("c3", "c5")}
+        extra = {cfg: run_extra_config(cfg) for cfg in ("c4", "c3", "c5")}
     boundary = None
     if not args.dry_run and not args.no_boundary and world == 1:
         boundary = {"process_block_latency": boundary_latency_subprocess()}
@@ -520,23 +612,26 @@ def main():
         win = jsg.window(jsg.capi.WIN_HANN, n)
         plan = jsg.Plan(n, win)
         n_samples = (F * hop + (n - hop) + 3) // 4 * 4
-        use_tail = (not c["colour"]) and (args.layout == "tail" or (args.layout == "auto" and args.config == "c2"))
+        per_ch = bool(c.get("per_channel"))
+        rows = C if per_ch else 1                         # output planes of one batch
+        use_tail = (not c["colour"]) and args.layout == "tail"      # (auto = reference: the reference's m_mem[col][bin], Spectrogram.h:144)
         ref_pitch = (H + 31) // 32 * 32
         pitch = n // 2 if use_tail else ref_pitch
         img_pitch = (F + 31) // 32 * 32
-        per_batch = C * n_samples * 4 + (H * img_pitch * 4 if c["colour"] else F * pitch * 4 + (F * 4 if use_tail else 0))
+        per_batch = C * n_samples * 4 + (H * img_pitch * 4 if c["colour"] else rows * (F * pitch * 4 + (F * 4 if use_tail else 0)))
         if not args.nbuf and abs(nbuf * per_batch - ROTATION_BYTES) > 0.25 * ROTATION_BYTES:   # (a changed geometry: keep ~1 GB)
             nbuf = max(2, int(ROTATION_BYTES // per_batch) + 1)
             bpd = nbuf if strided else 1
-        base = synth_audio(C, n_samples + nbuf * 64, fs=c["fs"], seed=1234 + 1000 * rank)   # SURVEY 8d signal
+        base = synth_audio(C, n_samples + nbuf * 64, fs=c["fs"], seed=1234 + 1000 * rank, first_channel=(rank * C if per_ch else 0))   # SURVEY 8d signal
         d_in = torch.empty((nbuf, C, n_samples), dtype=torch.float32, device="cuda")          # batch b = d_in[b]
         for b in range(nbuf):
             d_in[b].copy_(torch.from_numpy(np.ascontiguousarray(base[:, b * 64:b * 64 + n_samples])))
         d_img = torch.zeros((nbuf, H, img_pitch), dtype=torch.int32, device="cuda") if c["colour"] else None
-        d_out = None if c["colour"] else torch.empty((nbuf, F, pitch), dtype=torch.float32, device="cuda")
-        d_tail = torch.empty((nbuf, 1, F), dtype=torch.float32, device="cuda") if use_tail else None
+        out_shape = (nbuf, C, F, pitch) if per_ch else (nbuf, F, pitch)
+        d_out = None if c["colour"] else torch.empty(out_shape, dtype=torch.float32, device="cuda")
+        d_tail = torch.empty((nbuf, rows, F), dtype=torch.float32, device="cuda") if use_tail else None
         d_lut = torch.from_numpy(jsg.colormap_lut(256, jsg.capi.CM_JADE)).cuda() if c["colour"] else None
-        mixk = dict(feedblocks=fb, mix_mode=jsg.capi.MIX_ABSMEAN)
+        mixk = dict(feedblocks=fb, mix_mode=(jsg.capi.MIX_PER_CHANNEL if per_ch else jsg.capi.MIX_ABSMEAN))
         one = torch.cuda.Stream()
         if c["colour"]:
             if strided:
@@ -547,7 +642,7 @@ def main():
             kernel_label = "stft_db_kernel<Cfg4096B, AbsMean, ARGB out> (the workgroups colour their own columns)"
         else:
             kname = jsg.stft_db_strided_kernel_name(plan, d_in[:bpd], hop, F, d_out[:bpd], d_tail=(d_tail[:bpd] if use_tail else None), **mixk)
-            kernel_label = f"stft_db_kernel<{kname}, {'one channel per column' if C == 1 else 'AbsMean'}, dB out{', strided' if bpd > 1 else ''}{', tail plane' if use_tail else ''}>"
+            kernel_label = f"stft_db_kernel<{kname}, {'one channel per column' if C == 1 or per_ch else 'AbsMean'}, dB out{', strided' if bpd > 1 else ''}{', tail plane' if use_tail else ''}>"
 
         def dispatch(stream_handle, b=0):
             if c["colour"] and strided:
@@ -614,26 +709,34 @@ def main():
             s1.record(one)
         torch.cuda.synchronize()
         single_us = s0.elapsed_time(s1) * 1e3 / (8 * nbuf)
-    reference_layout_us = None
-    if not args.dry_run and strided and use_tail and not args.no_single:
-        # ---- the same dispatches with the reference's column layout (bin n/2 inline, 128-byte-aligned columns of n/2+1 floats rounded up
-        #      to 32): what the tail plane buys, measured in this process on this box ----
-        d_ref = torch.empty((nbuf, F, ref_pitch), dtype=torch.float32, device="cuda")
+    other_layout_us = None
+    if not args.dry_run and strided and not args.no_single and not c["colour"] and not c.get("per_channel") and world == 1:
+        # ---- the same dispatches with the OTHER column layout, measured in this process on this box.  The timed region writes the reference's
+        #      m_mem[col][bin] (bin n/2 inline: columns of n/2+1 floats at a pitch rounded up to 32 floats); the other one is the tail plane of
+        #      jsg_stft_args.out_tail (columns of exactly n/2 floats = whole 128-byte lines + a dense plane of bin n/2; same values) -- or the
+        #      reverse under --layout tail ----
+        if use_tail:
+            d_o, d_ot = torch.empty((nbuf, F, ref_pitch), dtype=torch.float32, device="cuda"), None
+        else:
+            d_o, d_ot = torch.empty((nbuf, F, n // 2), dtype=torch.float32, device="cuda"), torch.empty((nbuf, 1, F), dtype=torch.float32, device="cuda")
         with torch.cuda.stream(one):
             t_ref = time.perf_counter()
             while time.perf_counter() - t_ref < 0.3:        # the same settling as the main region: ~0.3 s of the work, then 5 timed steps
                 for _ in range(dps):
-                    jsg.stft_db_strided(plan, d_in, hop, F, d_ref, blocks_per_cu=args.blocks_per_cu, stream=one.cuda_stream, **mixk)
+                    jsg.stft_db_strided(plan, d_in, hop, F, d_o, d_tail=d_ot, blocks_per_cu=args.blocks_per_cu, stream=one.cuda_stream, **mixk)
                 torch.cuda.synchronize()
             r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             r0.record(one)
             for _ in range(5 * dps):
-                jsg.stft_db_strided(plan, d_in, hop, F, d_ref, blocks_per_cu=args.blocks_per_cu, stream=one.cuda_stream, **mixk)
+                jsg.stft_db_strided(plan, d_in, hop, F, d_o, d_tail=d_ot, blocks_per_cu=args.blocks_per_cu, stream=one.cuda_stream, **mixk)
             r1.record(one)
         torch.cuda.synchronize()
-        reference_layout_us = r0.elapsed_time(r1) * 1e3 / (5 * dps)
-        ref_same = bool(torch.equal(d_ref[..., :n // 2], d_out) and torch.equal(d_ref[..., n // 2], d_tail[:, 0, :]))
-        del d_ref
+        other_layout_us = r0.elapsed_time(r1) * 1e3 / (5 * dps)
+        if use_tail:
+            layouts_same = bool(torch.equal(d_o[..., :n // 2], d_out) and torch.equal(d_o[..., n // 2], d_tail[:, 0, :]))
+        else:
+            layouts_same = bool(torch.equal(d_out[..., :n // 2], d_o) and torch.equal(d_out[..., n // 2], d_ot[:, 0, :]))
+        del d_o, d_ot
     barrier(); sync()
     if dist is not None:
         t = torch.tensor([wall, dispatch_us or 0.0], dtype=torch.float64, device=red_dev)
@@ -666,13 +769,13 @@ def main():
                 d_out.fill_(-7.0)
                 dispatch(one.cuda_stream)
                 pin = 0 if n not in (2048, 4096) else (2 if "B," in kernel_label else 1)
-                tmp = torch.empty((F, ref_pitch), dtype=torch.float32, device="cuda")      # single launches in the REFERENCE layout
+                tmp = torch.empty(((C, F, ref_pitch) if per_ch else (F, ref_pitch)), dtype=torch.float32, device="cuda")      # single launches in the REFERENCE layout
                 differing = 0
                 for k in sorted({0, nbuf // 2, nbuf - 1}):
                     tmp.fill_(-7.0)
                     jsg.stft_db(plan, d_in[k], hop, F, tmp, plan_select=pin, stream=one.cuda_stream, **mixk)
                     if use_tail:
-                        differing += int((tmp[:, :n // 2] != d_out[k]).sum()) + int((tmp[:, n // 2] != d_tail[k, 0]).sum())
+                        differing += int((tmp[..., :n // 2] != d_out[k]).sum()) + int((tmp[..., n // 2] != d_tail[k].reshape(tmp[..., n // 2].shape)).sum())
                     else:
                         differing += int((tmp != d_out[k]).sum())
                 parity["strided_columns_differing_from_single_launches"] = differing
@@ -680,15 +783,20 @@ def main():
 
     units_total = world * args.steps * dps * bpd * units_per_batch
     algo = algo_batch * bpd                            # algorithmic bytes of one dispatch
-    unit_word = "columns" if c["colour"] or C > 1 else "frames"
+    per_ch = bool(c.get("per_channel"))
+    unit_word = (f"{C} channels x {F} frames" if per_ch else ("columns" if c["colour"] or C > 1 else "frames"))
+    workload = c["workload"]
+    if per_ch and world > 1:
+        workload += f" -- this run: {world} GPUs x {C} channels = {world * C} channels"
     out = {
         "metric": c["metric"], "value": None if args.dry_run else units_total / wall, "unit": c["unit"],
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": c["workload"],
-                   "step": f"{dps} dispatches x {bpd} {'images' if c['colour'] else 'batches'} x {F} {unit_word} = {dps * bpd * units_per_batch} {c['unit'].split('/')[0]} per step and GPU",
+        "config": {"workload": workload,
+                   "step": f"{dps} dispatches x {bpd} {'images' if c['colour'] else 'batches'} x {'' if per_ch else F}{'' if per_ch else ' '}{unit_word} = {dps * bpd * units_per_batch} {c['unit'].split('/')[0]} per step and GPU",
                    "dispatches_per_step": dps, "batches_per_dispatch": bpd, "frames_per_batch": F * C, "columns_per_batch": F, "frames_per_dispatch": F * C * bpd,
-                   "channels_per_gpu": C, "distinct_batches": nbuf, "rotation_bytes": None if args.dry_run else int(nbuf * per_batch),
+                   "channels_per_gpu": C, "channels_total": world * C if per_ch else C, "per_gpu_value": None if args.dry_run else units_total / wall / world,
+                   "distinct_batches": nbuf, "rotation_bytes": None if args.dry_run else int(nbuf * per_batch),
                    "hip_streams_per_gpu": 1, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                    "column_layout": None if args.dry_run else ("n/2 floats per column + dense plane of bin n/2 (jsg_stft_args.out_tail)" if use_tail else
                                                                ("ARGB image rows" if c["colour"] else "reference: n/2+1 floats per column, pitch rounded up to 32 floats")),
@@ -705,10 +813,10 @@ def main():
         achieved = algo / (dispatch_us * 1e-6) / 1e9
         conc = algo * dps * args.steps / wall / 1e9
         # HBM traffic (PMC) and the tracer's per-dispatch duration come from the rocprofv3 passes of tools/profile_bench.sh
-        # (profiles/r05_<cfg>_hbm_traffic.json): bench.py does not run counters itself.  The file carries the hash of the kernel sources
+        # (profiles/r06_<cfg>_hbm_traffic.json): bench.py does not run counters itself.  The file carries the hash of the kernel sources
         # it was recorded with; when that differs from this build's the figures are flagged as stale.
         traffic, tsrc, rocprof_us = None, None, None
-        prof = os.path.join(ROOT, "profiles", f"r05_{args.config}_hbm_traffic.json")
+        prof = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{args.config}_hbm_traffic.json")
         if os.path.exists(prof) and strided:
             try:
                 pj = json.load(open(prof))
@@ -733,17 +841,40 @@ def main():
             "second_roof": valu_roof(c, units_per_batch * bpd, dispatch_us, ((power or {}).get("path_sustained") or {}).get("sclk_MHz_median")),
             "commit": commit,
         }
-        if reference_layout_us:
-            out["roofline"]["reference_column_layout"] = {
-                "what": "the same strided dispatches writing the reference's column layout (bin n/2 inline: a 4-byte piece in one more 128-byte line per "
-                        "column) instead of columns of n/2 floats + a dense plane of bin n/2 (jsg_stft_args.out_tail); same values",
-                "avg_dispatch_us": reference_layout_us, "frac": algo / (reference_layout_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                "units_per_s": units_per_batch * bpd / (reference_layout_us * 1e-6), "values_identical_to_the_timed_layout": ref_same}
+        r = out["roofline"]
+        # ---- the qualifiers of the headline as SCALARS of `roofline` (a record that keeps only scalars keeps these) ----
+        r["column_layout"] = "tail_plane" if use_tail else ("argb_image" if c["colour"] else "reference")
+        r["second_roof_frac"] = r["second_roof"]["frac"]
+        r["second_roof_clock_GHz"] = r["second_roof"]["clock_GHz"]
+        r["traffic_over_algorithmic"] = (traffic / algo) if traffic else None
+        r["traffic_matches_this_build"] = bool(tsrc and tsrc["matches_this_build"])
+        if not c["colour"]:
+            r["frac_reference_layout" if not use_tail else "frac_tail_plane"] = frac
+        if other_layout_us:
+            of = algo / (other_layout_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+            r["frac_tail_plane" if not use_tail else "frac_reference_layout"] = of
+            r["other_column_layout"] = {
+                "what": ("the same strided dispatches writing columns of n/2 floats + a dense plane of bin n/2 (jsg_stft_args.out_tail) instead of the "
+                         "reference's m_mem[col][bin] (bin n/2 inline: a 4-byte piece in one more 128-byte line per column); same values; a host that "
+                         "wants the reference shape back pays one more pass (jsg_columns_from_tail_layout_launch)") if not use_tail else
+                        "the same strided dispatches writing the reference's column layout (bin n/2 inline) instead of the tail plane; same values",
+                "layout": "reference" if use_tail else "tail_plane",
+                "avg_dispatch_us": other_layout_us, "frac": of, "units_per_s": units_per_batch * bpd / (other_layout_us * 1e-6),
+                "values_identical_to_the_timed_layout": layouts_same}
         if single_us:
-            out["roofline"]["one_batch_per_dispatch"] = {
-                "what": f"the same batches, ONE jsg_stft_db_launch per {F}-frame batch, in order on one stream (hipGraph replay of the rotation, HIP events)",
-                "avg_dispatch_us": single_us, "algorithmic_bytes_per_dispatch": algo_batch, "frac": algo_batch / (single_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            r["frac_one_batch_per_dispatch"] = algo_batch / (single_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+            r["one_batch_per_dispatch_units_per_s"] = units_per_batch / (single_us * 1e-6)
+            r["one_batch_per_dispatch"] = {
+                "what": f"the same batches, ONE jsg_stft_db_launch per {F}-frame batch, in order on one stream (hipGraph replay of the rotation, HIP events): "
+                        "the literal 'batched 4096 frames/launch' of BASELINE configs[1]",
+                "avg_dispatch_us": single_us, "algorithmic_bytes_per_dispatch": algo_batch, "frac": r["frac_one_batch_per_dispatch"],
                 "units_per_s": units_per_batch / (single_us * 1e-6)}
+        if extra is not None:
+            for cfg in ("c3", "c4", "c5"):
+                e = extra.get(cfg) or {}
+                r[f"extra_{cfg}_frac"] = (e.get("roofline") or {}).get("frac")
+                r[f"extra_{cfg}_value"] = e.get("value")
+                r[f"extra_{cfg}_second_roof_frac"] = ((e.get("roofline") or {}).get("second_roof") or {}).get("frac")
     if power is not None:
         out["power"] = power
     if calibration is not None:

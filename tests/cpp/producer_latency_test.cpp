@@ -110,10 +110,19 @@ int main(int argc, char** argv) {
     // ordinary private buffer and one atomic is touched -- no library, no page-locked memory, no other thread -- and timed the same way.  A
     // tail that the control shows too belongs to the box (interrupt handlers and hypervisor time are charged to whatever thread is running
     // and are NOT context switches), not to jsg_process_block.
+    // Round 6: the ORDER of call and control alternates from block to block.  Whatever runs FIRST after the pacing sleep
+    // meets the wake-up's leftovers (the timer interrupt's soft-irq work, a core coming out of an idle state, cold caches and TLB); whatever
+    // runs second runs warm.  A control that always ran second could never show that tail.  With the order alternating, each of the two is
+    // "first after the sleep" in half of the blocks, and the claim "the tail belongs to the box, not to jsg_process_block" becomes a relation
+    // that can be asserted: per position, the call's count of long executions is of the order of the control's -- else the call is at fault.
     std::vector<float> ctrl_dst(size_t(C) * N);
     std::atomic<unsigned long long> ctrl_word{0};
     size_t ctrl_over50 = 0, ctrl_cpu_over50 = 0;
     double ctrl_max = 0.0;
+    size_t pos_over50[2][2] = {{0, 0}, {0, 0}}, pos_cpu_over50[2][2] = {{0, 0}, {0, 0}}, pos_n[2][2] = {{0, 0}, {0, 0}};   // [what: 0 call, 1 control][position: 0 first, 1 second]
+    double pos_max[2][2] = {{0, 0}, {0, 0}};
+    std::vector<double> ctrl_lat;
+    ctrl_lat.reserve(size_t(blocks));
     // interrupts served by the producer's CPU during the run (/proc/interrupts, the column of that CPU)
     auto irqs_on_cpu = [](int cpu) -> long long {
         FILE* f = std::fopen("/proc/interrupts", "r");
@@ -142,30 +151,47 @@ int main(int argc, char** argv) {
     const long nivcsw_before = nivcsw();
     for (int b = 0; b < blocks; ++b) {
         const float* ptrs[2] = {x.data() + size_t(b % period) * N, x.data() + chan_pitch + size_t(b % period) * N};
-        const long sw0 = nivcsw();
-        const double c0 = thread_cpu_us();
-        const auto t0 = std::chrono::steady_clock::now();
-        const int rc = jsg_process_block(live, ptrs);
-        const auto t1 = std::chrono::steady_clock::now();
-        const double c1 = thread_cpu_us();
-        const long sw1 = nivcsw();
-        if (rc < 0) { std::fprintf(stderr, "process_block: %s\n", jsg_last_error(live)); stop = true; consumer.join(); return 2; }
-        lat.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
-        cpu.push_back(c1 - c0);
-        switched.push_back(sw1 != sw0);
-        {   // the control: the same bytes into private memory, timed the same way
-            const double k0 = thread_cpu_us();
-            const auto u0 = std::chrono::steady_clock::now();
-            ctrl_word.fetch_add(1);
-            for (int c = 0; c < C; ++c) std::memcpy(ctrl_dst.data() + size_t(c) * N, ptrs[c], size_t(N) * sizeof(float));
-            ctrl_word.fetch_add(1);
-            const auto u1 = std::chrono::steady_clock::now();
-            const double k1 = thread_cpu_us();
-            const double w = std::chrono::duration<double, std::micro>(u1 - u0).count();
-            if (b > 0) {
-                ctrl_over50 += w > 50.0;
-                ctrl_cpu_over50 += (k1 - k0) > 50.0;
-                ctrl_max = std::max(ctrl_max, w);
+        const int control_first = b & 1;
+        for (int step = 0; step < 2; ++step) {
+            const bool is_control = (step == 0) == (control_first != 0);
+            if (!is_control) {
+                const long sw0 = nivcsw();
+                const double c0 = thread_cpu_us();
+                const auto t0 = std::chrono::steady_clock::now();
+                const int rc = jsg_process_block(live, ptrs);
+                const auto t1 = std::chrono::steady_clock::now();
+                const double c1 = thread_cpu_us();
+                const long sw1 = nivcsw();
+                if (rc < 0) { std::fprintf(stderr, "process_block: %s\n", jsg_last_error(live)); stop = true; consumer.join(); return 2; }
+                const double w = std::chrono::duration<double, std::micro>(t1 - t0).count();
+                lat.push_back(w);
+                cpu.push_back(c1 - c0);
+                switched.push_back(sw1 != sw0);
+                if (b > 0) {
+                    ++pos_n[0][step];
+                    pos_over50[0][step] += w > 50.0;
+                    pos_cpu_over50[0][step] += (c1 - c0) > 50.0;
+                    pos_max[0][step] = std::max(pos_max[0][step], w);
+                }
+            } else {   // the control: the same bytes into private memory, timed the same way
+                const double k0 = thread_cpu_us();
+                const auto u0 = std::chrono::steady_clock::now();
+                ctrl_word.fetch_add(1);
+                for (int c = 0; c < C; ++c) std::memcpy(ctrl_dst.data() + size_t(c) * N, ptrs[c], size_t(N) * sizeof(float));
+                ctrl_word.fetch_add(1);
+                const auto u1 = std::chrono::steady_clock::now();
+                const double k1 = thread_cpu_us();
+                const double w = std::chrono::duration<double, std::micro>(u1 - u0).count();
+                ctrl_lat.push_back(w);
+                if (b > 0) {
+                    ctrl_over50 += w > 50.0;
+                    ctrl_cpu_over50 += (k1 - k0) > 50.0;
+                    ctrl_max = std::max(ctrl_max, w);
+                    ++pos_n[1][step];
+                    pos_over50[1][step] += w > 50.0;
+                    pos_cpu_over50[1][step] += (k1 - k0) > 50.0;
+                    pos_max[1][step] = std::max(pos_max[1][step], w);
+                }
             }
         }
         if (pace_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(pace_us));
@@ -186,6 +212,8 @@ int main(int argc, char** argv) {
             cpu_max_of_long = std::max(cpu_max_of_long, cpu[i]);
         }
     }
+    std::sort(ctrl_lat.begin(), ctrl_lat.end());
+    const double ctrl_p50 = ctrl_lat.empty() ? 0.0 : ctrl_lat[ctrl_lat.size() / 2];
     std::vector<double> cpu_sorted(cpu);
     std::sort(cpu_sorted.begin(), cpu_sorted.end());
     stop = true;
@@ -227,11 +255,19 @@ int main(int argc, char** argv) {
                 "\"long_wall_calls_after_first\": %zu, \"long_wall_calls_with_involuntary_switch\": %zu, \"long_wall_calls_long_in_thread_cpu_too\": %zu, "
                 "\"thread_cpu_max_of_long_wall_calls_us\": %.1f, \"involuntary_switches_total\": %ld, "
                 "\"control_copy_calls_over_50us\": %zu, \"control_copy_thread_cpu_over_50us\": %zu, \"control_copy_max_us\": %.1f, "
+                "\"control_copy_p50_us\": %.2f, "
+                "\"first_after_sleep\": {\"call_n\": %zu, \"call_over_50us\": %zu, \"call_thread_cpu_over_50us\": %zu, \"call_max_us\": %.1f, "
+                "\"control_n\": %zu, \"control_over_50us\": %zu, \"control_thread_cpu_over_50us\": %zu, \"control_max_us\": %.1f}, "
+                "\"second_after_sleep\": {\"call_n\": %zu, \"call_over_50us\": %zu, \"call_thread_cpu_over_50us\": %zu, \"call_max_us\": %.1f, "
+                "\"control_n\": %zu, \"control_over_50us\": %zu, \"control_thread_cpu_over_50us\": %zu, \"control_max_us\": %.1f}, "
                 "\"producer_cpu\": %d, \"interrupts_on_producer_cpu_during_run\": %lld}\n",
                 blocks, W, H, reads.load(), pct(0.5), pct(0.99), pct(0.9999), lat.back(), first_us, max_after_first, worst_at, over50, dropped, pa, pr, diff_floats, diff_px,
                 cpu_sorted[size_t(0.5 * double(cpu_sorted.size() - 1))], cpu_sorted[size_t(0.9999 * double(cpu_sorted.size() - 1))], cpu_max, cpu_over_50,
                 long_calls, long_with_switch, long_cpu_over_50, cpu_max_of_long, nivcsw_total,
-                ctrl_over50, ctrl_cpu_over50, ctrl_max, my_cpu, (irq_before >= 0 && irq_after >= 0) ? irq_after - irq_before : -1LL);
+                ctrl_over50, ctrl_cpu_over50, ctrl_max, ctrl_p50,
+                pos_n[0][0], pos_over50[0][0], pos_cpu_over50[0][0], pos_max[0][0], pos_n[1][0], pos_over50[1][0], pos_cpu_over50[1][0], pos_max[1][0],
+                pos_n[0][1], pos_over50[0][1], pos_cpu_over50[0][1], pos_max[0][1], pos_n[1][1], pos_over50[1][1], pos_cpu_over50[1][1], pos_max[1][1],
+                my_cpu, (irq_before >= 0 && irq_after >= 0) ? irq_after - irq_before : -1LL);
     jsg_destroy(live);
     jsg_destroy(batch);
     return 0;

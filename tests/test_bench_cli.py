@@ -56,13 +56,70 @@ def test_two_ranks_dry_run_over_gloo():
     assert j["n_gpus"] == 2 and j["steps"] == 4 and j["dry_run"] is True and j["ms_per_step"] > 0
 
 
+def test_plain_gpus_2_starts_its_own_ranks_and_times_configs3():
+    """`python bench.py --gpus N` with NO launcher around it -- the parent (which never imports torch or touches a GPU) starts the
+    N ranks itself, rank 0's line comes through, and the N > 1 default workload is BASELINE configs[3]: 8 channels per GPU, one column per channel."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert REQUIRED <= set(j) and j["n_gpus"] == 2 and j["steps"] == 3 and j["dry_run"] is True and j["scaling"] == "weak"
+    assert j["config"]["workload"].startswith("configs[3]") and "2 GPUs x 8 channels = 16 channels" in j["config"]["workload"]
+    assert j["config"]["channels_per_gpu"] == 8 and j["config"]["channels_total"] == 16 and j["config"]["frames_per_batch"] == 8 * 4096
+    assert j["metric"] == "STFT frames/sec (1024-pt, 50% hop)"
+
+
+def test_the_parent_of_a_self_started_run_does_not_import_torch():
+    """... and cannot have initialised the GPU: the spawn happens before bench.py's first `import torch`."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    assert main.index("spawn_ranks(args.gpus") < main.index("import torch")
+    body = src[src.index("def spawn_ranks("):src.index("def main():")]
+    assert "import torch" not in body and "os.exec" not in body and "subprocess.run" in body
+
+
+def test_algorithmic_bytes_of_every_config():
+    import bench
+    assert bench.algorithmic_bytes_per_batch(bench.CONFIGS["c2"]) == 4096 * 4100
+    assert bench.algorithmic_bytes_per_batch(bench.CONFIGS["c3"]) == 4096 * 20484
+    assert bench.algorithmic_bytes_per_batch(bench.CONFIGS["c4"]) == 8 * 4096 * 4100          # SURVEY 8d: "C4: as C2 per channel-frame"
+    assert bench.algorithmic_bytes_per_batch(bench.CONFIGS["c5"]) == 1875 * 12292
+
+
 @pytest.mark.gpu
 def test_two_ranks_share_one_gpu_and_run_the_kernels():
-    j = _run(_torchrun(2, ["--steps", "2", "--warmup", "1", "--dispatches-per-step", "2", "--nbuf", "8", "--no-cpu-baseline"]),
+    j = _run(_torchrun(2, ["--config", "c2", "--steps", "2", "--warmup", "1", "--dispatches-per-step", "2", "--nbuf", "8", "--no-cpu-baseline"]),
              env={"JSG_BENCH_BACKEND": "gloo"})
     assert REQUIRED <= set(j) and j["n_gpus"] == 2 and j["value"] > 1e7            # north_star's >= 1e7 frames/s, whole job
     assert j["config"]["dispatches_per_step"] == 2 and j["config"]["batches_per_dispatch"] == 8 and j["roofline"]["avg_dispatch_us"] > 0
     assert abs(j["ms_per_step"] * j["steps"] * 1e-3 * j["value"] - 2 * 2 * 2 * 8 * 4096) < 1.0   # value = all ranks' frames / timed wall
+
+
+@pytest.mark.gpu
+def test_two_ranks_default_to_configs3_and_run_the_per_channel_kernels():
+    """The N > 1 default (configs[3]): two ranks share the one GPU of the test box over gloo, 8 channels each, one column per channel."""
+    j = _run(_torchrun(2, ["--steps", "2", "--warmup", "1", "--dispatches-per-step", "2", "--nbuf", "3", "--no-cpu-baseline"]),
+             env={"JSG_BENCH_BACKEND": "gloo"})
+    assert j["n_gpus"] == 2 and j["config"]["workload"].startswith("configs[3]") and j["config"]["channels_total"] == 16
+    assert "Cfg1024" in j["roofline"]["kernel"] and "one channel per column" in j["roofline"]["kernel"]
+    assert j["roofline"]["algorithmic_bytes_per_dispatch"] == 3 * 8 * 4096 * 4100
+    assert abs(j["ms_per_step"] * j["steps"] * 1e-3 * j["value"] - 2 * 2 * 2 * 3 * 8 * 4096) < 1.0
+    assert abs(j["config"]["per_gpu_value"] * 2 - j["value"]) < 1e-3 * j["value"]
+
+
+@pytest.mark.gpu
+def test_c4_shard_line_on_one_gpu():
+    j = _run([sys.executable, "bench.py", "--config", "c4", "--steps", "2", "--warmup", "1", "--dispatches-per-step", "2", "--no-cpu-baseline", "--no-calibration",
+              "--no-boundary"])
+    k = j["config"]["batches_per_dispatch"]
+    assert j["unit"] == "frames/s" and j["value"] > 1e7 and k >= 8 and j["config"]["column_layout"].startswith("reference")
+    assert j["roofline"]["algorithmic_bytes_per_dispatch"] == k * 8 * 4096 * 4100 and 0.05 < j["roofline"]["frac"] < 1.0
+    assert j["parity"]["kernel"] == "Cfg1024" and j["parity"]["max_rel_power_err_bins_within_20dB_of_peak"] < 1e-5
+    assert j["parity"]["strided_columns_differing_from_single_launches"] == 0
+    assert j["parity"]["colour_index_flips_end_to_end"] <= max(4, j["parity"]["pixels_checked"] // 50000)
+    assert abs(j["ms_per_step"] * j["steps"] * 1e-3 * j["value"] - 2 * 2 * k * 8 * 4096) < 1.0
 
 
 @pytest.mark.gpu
@@ -108,6 +165,13 @@ def test_default_config_line_carries_roofline_calibration_boundary_and_the_other
     assert (r["frac_rocprof"] is not None) == bool(r["traffic_source"] and r["traffic_source"]["matches_this_build"])
     assert r["second_roof"]["bound"] == "valu_issue" and "Cfg1024" in r["kernel"]
     assert 0.2 < r["one_batch_per_dispatch"]["frac"] < r["frac"]
+    # the headline is the reference's column layout, and every qualifier is a SCALAR of `roofline`
+    assert r["column_layout"] == "reference" and j["config"]["column_layout"].startswith("reference") and r["frac_reference_layout"] == r["frac"]
+    assert 0.2 < r["frac_tail_plane"] < 1.0 and r["other_column_layout"]["values_identical_to_the_timed_layout"] is True
+    assert r["frac_one_batch_per_dispatch"] == r["one_batch_per_dispatch"]["frac"] and r["second_roof_frac"] == r["second_roof"]["frac"]
+    for cfg in ("c3", "c4", "c5"):
+        assert isinstance(r[f"extra_{cfg}_frac"], float) and r[f"extra_{cfg}_frac"] == j["extra"][cfg]["roofline"]["frac"]
+        assert r[f"extra_{cfg}_value"] == j["extra"][cfg]["value"]
     cal = j["calibration"]
     assert 4000.0 < cal["peak_copy_GBps"] < 8000.0 and cal["sizes"]["8.4MB"]["GBps"] < cal["peak_copy_GBps"]
     assert j["config"]["GPU_MAX_HW_QUEUES"] is None and "jsg_stft_db_launch_strided" in j["config"]["issue"]
@@ -116,7 +180,7 @@ def test_default_config_line_carries_roofline_calibration_boundary_and_the_other
     b = j["boundary"]
     assert b["process_block_latency"]["ring_bit_identical_to_undisturbed_batch_run"] is True and b["process_block_latency"]["p50_us"] < 100.0
     assert b["pcie_inclusive_rate"]["host_memory"]["pinned"]["frames_per_s"] > 1e6
-    for cfg, kern in (("c3", "Cfg2048B"), ("c5", "Cfg4096B")):
+    for cfg, kern in (("c3", "Cfg2048B"), ("c5", "Cfg4096B"), ("c4", "Cfg1024")):
         e = j["extra"][cfg]
         assert "error" not in e, e
         assert e["value"] > 1e6 and kern in e["kernel"] and 0.05 < e["roofline"]["frac"] < 1.0
