@@ -538,7 +538,11 @@ int jsg_process_block_sharded(jsg_engine* const* engines, const int* first_chann
     for (int i = 0; i < n_devices; ++i) {
         if (!engines[i]) continue;
         const int arc = engines[i]->async_rc.load(std::memory_order_acquire);
-        if (arc != 0) return arc;
+        if (arc != 0) {   // an engine with a stored worker error takes nothing any more: no shard gets the block, every shard counts it
+            for (int k = 0; k < n_devices; ++k)
+                if (engines[k]) engines[k]->q.dropped.fetch_add(1, std::memory_order_relaxed);
+            return arc;
+        }
         if (!engines[i]->q.can_push(0, 0)) all = false;
     }
     if (!all) {
@@ -550,6 +554,9 @@ int jsg_process_block_sharded(jsg_engine* const* engines, const int* first_chann
     for (int i = 0; i < n_devices; ++i) {
         if (!engines[i]) continue;
         const int rc = jsg_process_block(engines[i], planar + first_channel[i]);
+        // (a worker error that appears between the scan above and this push: the shards before i have taken the block and cannot give it
+        //  back; the error is final for that engine -- every later call returns it before anything is pushed -- so the set is out of step by at
+        //  most this one block, and the caller is told with the error code)
         if (rc < 0) return rc;
         if (rc > worst) worst = rc;
     }

@@ -13,7 +13,7 @@
 // Finite, non-negative inputs only (what |X|^2 produces); no NaN / infinity handling.
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define JSG_EXACT_HD __host__ __device__ __forceinline__
 #else
 #define JSG_EXACT_HD static inline

@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void db_from_power_kernel(const float* p, floa
 }
 
 // jsg_columns_from_tail_layout_launch: the reference's dense [W][n/2+1] shape (m_mem[col][bin], Spectrogram.h:144) out of the tail-plane
-// layout of jsg_stft_args.out_tail -- columns of n/2 floats + a plane of bin n/2.  One workgroup per column, 16 bytes per thread and step.
+// layout of jsg_stft_args.out_tail -- columns of n/2 floats + a plane of bin n/2.  One workgroup per column, one float per thread and step
+// (dense destination columns of n/2+1 floats start 4 bytes further off a 16-byte boundary from column to column: no wider store fits them all).
 __global__ __launch_bounds__(256) void tail_merge_kernel(const float* __restrict__ db, long long db_pitch, const float* __restrict__ tail, int half,
                                                          float* __restrict__ dst, long long dst_pitch) {
     const long long col = blockIdx.x;
@@ -301,7 +302,7 @@ struct IndexOut {   // fused display path: where and how the palette indices of 
 // 2048 points: does this launch take the pair plan (Cfg2048P: a channel PAIR as one complex transform)?  Sum-type mixes (AbsMean, Sum)
 // over an EVEN number of channels, float columns (not the display launches), and -- like the "B" kernels, it runs one 8-wave workgroup
 // per CU, here of eight columns -- launches that fill their rounds.  plan_select = 3 pins it where it applies (else: as 0).
-constexpr bool kPairPlanByDefault = false;  // automatic selection: measured ahead of Cfg2048B where it applies
+constexpr bool kPairPlanByDefault = false;  // opt-in only (plan_select = 3): measured 20 % BEHIND Cfg2048B on the C3 dispatch (537 vs 446 us)
 static bool wants_plan_pair(int n, const jsg_stft_args* g, int n_cu, bool display, long long frames_of_launch = -1) {
     if (n != 2048 || display) return false;
     if (g->mix_mode != JSG_MIX_ABSMEAN && g->mix_mode != JSG_MIX_SUM) return false;

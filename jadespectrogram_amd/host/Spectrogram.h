@@ -57,17 +57,18 @@ public:
         for (size_t c = 0; c < ch; ++c) m_ptrs[c] = data[c].data();
         // An offline bounce (setNonRealtime(true)) may run faster than the GPU takes blocks out: there the call waits for a free slot
         // instead of dropping -- the reference never loses a block (Spectrogram.cpp:37-135).
-        if (m_nonRealtime.load(std::memory_order_relaxed))
-            return jsg_process_block_wait(m_engine.get(), m_ptrs.data(), int(ch), int(data[0].size()), m_nonRealtimeTimeoutMs);
+        if (m_nonRealtime.load(std::memory_order_acquire))   // (acquire: pairs with setNonRealtime's release, the timeout below is the one stored before it)
+            return jsg_process_block_wait(m_engine.get(), m_ptrs.data(), int(ch), int(data[0].size()), m_nonRealtimeTimeoutMs.load(std::memory_order_relaxed));
         return jsg_process_block_n(m_engine.get(), m_ptrs.data(), int(ch), int(data[0].size()));
     }
     long long droppedBlocks() const { return jsg_get_dropped_blocks(m_engine.get()); }   // blocks the engine did not take (see above)
     // Mirror of juce::AudioProcessor::setNonRealtime: the processor forwards its own flag (prepareToPlay / processBlock:
     // m_spectrogram.setNonRealtime(isNonRealtime())).  false (default): wait-free and lossy when the ring is full (a live host);
-    // true: lossless, the call may wait up to timeoutMs (< 0: no limit) for the engine's worker.
-    void setNonRealtime(bool nonRealtime, int timeoutMs = -1) {
-        m_nonRealtimeTimeoutMs = timeoutMs;
-        m_nonRealtime.store(nonRealtime, std::memory_order_relaxed);
+    // true: lossless, the call may wait up to timeoutMs for the engine's worker (default 5 s: a worker that stalls -- a hung GPU -- must not
+    // hold the host's render thread forever; the block then counts as dropped and 1 is returned; < 0: no limit, the caller's choice).
+    void setNonRealtime(bool nonRealtime, int timeoutMs = 5000) {
+        m_nonRealtimeTimeoutMs.store(timeoutMs, std::memory_order_relaxed);
+        m_nonRealtime.store(nonRealtime, std::memory_order_release);
     }
     // Spectrogram::prepareParameter (reference Spectrogram.cpp:25-35): remember where the four display parameters live.
     // Nothing on the GPU depends on them; the IDs and defaults are those of reference Spectrogram.h:22-58
@@ -153,7 +154,7 @@ private:
     }
     std::unique_ptr<jsg_engine, Deleter> m_engine;
     std::atomic<bool> m_nonRealtime{false};
-    int m_nonRealtimeTimeoutMs = -1;
+    std::atomic<int> m_nonRealtimeTimeoutMs{5000};
     std::vector<const float*> m_ptrs;
     std::vector<float*> m_rows;
     std::string m_lastError;

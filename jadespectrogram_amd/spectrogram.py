@@ -289,14 +289,21 @@ def stft_db(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: int
     check(lib().jsg_stft_db_launch(plan._p, C.byref(a), C.c_void_p(stream)))
 
 
-def columns_from_tail_layout(d_db, d_tail, d_dst, *, stream: int | None = None):
+def columns_from_tail_layout(d_db, d_tail, d_dst, *, n: int | None = None, stream: int | None = None):
     """jsg_columns_from_tail_layout_launch: d_db [W][pitch >= n/2] + d_tail [W] (the tail-plane layout of stft_db(..., d_tail=)) -> d_dst [W][>= n/2+1],
-    the reference's dense column shape (what getMem hands out)."""
+    the reference's dense column shape (what getMem hands out).  `n` = the FFT size (a Plan's .n); without it the rows of d_db must be
+    exactly n/2 floats wide (the shape stft_db's tail layout is normally given) -- the height is never guessed from padded rows."""
     import torch
     assert d_db.is_cuda and d_tail.is_cuda and d_dst.is_cuda and d_db.dim() == 2 and d_dst.dim() == 2 and d_db.stride(1) == 1 and d_dst.stride(1) == 1
     W = d_db.shape[0]
     assert d_tail.numel() == W and d_tail.is_contiguous() and d_dst.shape[0] == W
-    H = min(d_db.shape[1], d_dst.shape[1] - 1) + 1
+    if n is None:
+        n = 2 * d_db.shape[1]
+        if n < 2 or n & (n - 1):
+            raise JsgError(capi.JSG_ERR_INVALID, f"columns_from_tail_layout: rows of {d_db.shape[1]} floats are not n/2 of a power-of-two FFT size; pass n=")
+    H = n // 2 + 1
+    if d_db.shape[1] < H - 1 or d_dst.shape[1] < H:
+        raise JsgError(capi.JSG_ERR_INVALID, f"columns_from_tail_layout: n = {n} needs source rows of >= {H - 1} and destination rows of >= {H} floats")
     if stream is None:
         stream = torch.cuda.current_stream(d_db.device).cuda_stream
     check(lib().jsg_columns_from_tail_layout_launch(d_db.data_ptr(), d_db.stride(0), d_tail.data_ptr(), W, H, d_dst.data_ptr(), d_dst.stride(0), C.c_void_p(stream)))
@@ -378,7 +385,8 @@ def _stft_args(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: 
     a.linear_out = int(bool(linear_out))
     a.blocks_per_cu = int(blocks_per_cu)
     a.exact_log = int(bool(exact_log))     # dB by the shared float32 routine (bit-reproducible on a CPU) instead of v_log_f32
-    a.plan_select = int(plan_select)       # 0 automatic, 1 small-workgroup kernel, 2 "B" kernel (2048 / 4096 points)
+    a.plan_select = int(plan_select)       # 0 automatic, 1 small-workgroup kernel, 2 "B" kernel (2048 / 4096 points), 3 pair plan (2048 points, even channel
+                                           # counts, sum-type mixes), 4 two-stage kernel (1024 points; include/jsg.h)
     if d_tail is not None:
         assert d_tail.is_cuda and d_tail.dtype == torch.float32 and d_tail.is_contiguous() and d_tail.shape[-1] == d_out.shape[-2]
         a.out_tail = d_tail.data_ptr()

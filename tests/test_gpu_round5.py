@@ -326,6 +326,15 @@ def test_columns_from_tail_layout_gives_the_reference_shape(jsg, oracle, torch_c
     assert torch.equal(got, ref[:, :513])
     with pytest.raises(jsg.capi.JsgError):      # a destination that cannot hold n/2 + 1 floats per column
         jsg.capi.check(jsg.capi.lib().jsg_columns_from_tail_layout_launch(dense.data_ptr(), 512, tail.data_ptr(), W, 513, got.data_ptr(), 512, None))
+    # padded rows on BOTH sides (pitch 544 and 544) -- the height comes from n, never from the row widths
+    dense_p = torch.full((W, 544), -120.0, device="cuda")
+    jsg.stft_db(plan, d_x, hop, F, dense_p, d_tail=tail, ring_pos=pos)
+    got_p = torch.full((W, 544), 3.0, device="cuda")
+    jsg.columns_from_tail_layout(dense_p, tail[0], got_p, n=n)
+    torch.cuda.synchronize()
+    assert torch.equal(got_p[:, :513], ref[:, :513]) and bool((got_p[:, 513:] == 3.0).all())
+    with pytest.raises(jsg.capi.JsgError):      # padded source rows and no n: refused instead of guessed
+        jsg.columns_from_tail_layout(dense_p, tail[0], got_p)
 
 
 # ---- round 5: the palette index without the two selects, where the value range allows it (color_index2_fast / cmap_is_fast) ----

@@ -1,5 +1,5 @@
 import json, os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import jadespectrogram_amd as jsg
 if os.environ.get("SP_LIB"):

@@ -1,3 +1,4 @@
+#!/bin/bash
 cd $GRAFT_REPO_ROOT
 for r in 1 2; do
 for v in product xcd3 xcd4 xcd6 xcd7 xcd8; do
