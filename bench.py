@@ -18,8 +18,8 @@ order, issued by plain C calls -- no extra streams, no hardware-queue setting, n
       tail-plane layout of jsg_stft_args.out_tail is timed beside it (roofline.frac_tail_plane), as is the literal one batch per
       dispatch (roofline.frac_one_batch_per_dispatch).
   c4 (default at N > 1, configs[3]: 64 channels sharded 8 per GPU): every rank holds 8 channels and writes one dB column PER CHANNEL
-      (JSG_MIX_PER_CHANNEL; the reference's channel loop Spectrogram.cpp:52-59 without the mix of :64-76); one step = 10 dispatches x
-      12 batches x 8 channels x 4096 frames; 4100 algorithmic bytes per channel-frame.  The N = 1 line carries one GPU's shard as extra.c4.
+      (JSG_MIX_PER_CHANNEL; the reference's channel loop Spectrogram.cpp:52-59 without the mix of :64-76); one step = 16 dispatches x
+      8 batches x 8 channels x 4096 frames; 4100 algorithmic bytes per channel-frame.  The N = 1 line carries one GPU's shard as extra.c4.
   c3 (configs[2]: 8 channels, 2048 points, 75 % overlap, AbsMean): one step = 4 dispatches x 12 batches x 4096 columns.
   c5 (configs[4]: stereo 96 kHz, 4096 points, 87.5 % overlap -> ARGB): one step = 3 dispatches of jsg_stft_image_launch_strided,
       each a whole rotation of ~44 independent 1875-column images.
@@ -71,7 +71,7 @@ CONFIGS = {
                workload="configs[2]: 8-channel 48 kHz, 2048-pt FFT, 512 hop (75 % overlap), Hann, AbsMean mix, 4096 columns/launch"),
     # configs[3]: the shard ONE GPU holds of the 64-channel stream (8 channels per GPU at N = 8), one column PER CHANNEL (the reference's channel loop,
     # Spectrogram.cpp:52-59, without the mix of :64-76 -- channels are independent up to there): rows = batch x channel of a strided dispatch
-    "c4": dict(n=1024, hop=512, channels=8, frames=4096, fs=48000.0, colour=False, per_channel=True, dispatches_per_step=10, batches_per_dispatch=12,
+    "c4": dict(n=1024, hop=512, channels=8, frames=4096, fs=48000.0, colour=False, per_channel=True, dispatches_per_step=16, batches_per_dispatch=8,
                metric="STFT frames/sec (1024-pt, 50% hop)", unit="frames/s",
                workload="configs[3]: 64-channel synthetic 48 kHz, 1024-pt FFT, 512 hop, Hann, sharded 8 channels per GPU (this GPU's shard: 8 channels, "
                         "one dB column per channel and frame, JSG_MIX_PER_CHANNEL), batches of 4096 frames per channel, no data-path collective"),

@@ -182,7 +182,7 @@ struct jsg_plan {
     int device = -1;
     float2* d_tab = nullptr;
     size_t tab_elems = 0;
-    float2* d_tab_b = nullptr;   // 2048 / 4096 points: lane tables of the second plan (Cfg2048B / Cfg4096B), behind d_tab in the same allocation
+    float2* d_tab_b = nullptr;   // 1024 / 2048 / 4096 points: lane tables of the second plan (Cfg1024B / Cfg2048B / Cfg4096B), behind d_tab in the same allocation
     float2* d_tab_p = nullptr;   // 2048 points: lane tables of the pair plan (Cfg2048P), behind those
 };
 
@@ -206,7 +206,15 @@ int jsg_plan_create(jsg_plan** out, int n, const float* window, float power_scal
     const double amp = std::sqrt(double(power_scale));   // |FFT(a w x)|^2 = a^2 |FFT(w x)|^2
     switch (n) {
         case 512: fill_tables<Cfg512>(t, window, amp); break;
-        case 1024: fill_tables<Cfg1024>(t, window, amp); break;
+        case 1024: {   // the three-stage plan and, behind it, the two-stage one (Cfg1024B)
+            fill_tables<Cfg1024>(t, window, amp);
+            std::vector<float2> tb;
+            fill_tables<Cfg1024B>(tb, window, amp);
+            t.resize((t.size() + 31) / 32 * 32, make_float2(0.f, 0.f));
+            tab_b_at = t.size();
+            t.insert(t.end(), tb.begin(), tb.end());
+            break;
+        }
         case 2048: {   // both 2048-point plans (the launcher picks per launch); the second table set starts 256-byte aligned
             fill_tables<Cfg2048>(t, window, amp);
             std::vector<float2> tb;
@@ -252,7 +260,7 @@ int jsg_plan_create(jsg_plan** out, int n, const float* window, float power_scal
     hipError_t err = hipSuccess;
     switch (n) {
         case 512: err = ensure_attrs_Cfg512(); break;
-        case 1024: err = ensure_attrs_Cfg1024(); if (err == hipSuccess) err = ensure_attrs_Cfg1024I(); break;
+        case 1024: err = ensure_attrs_Cfg1024(); if (err == hipSuccess) err = ensure_attrs_Cfg1024I(); if (err == hipSuccess) err = ensure_attrs_Cfg1024B(); break;
         case 2048: err = ensure_attrs_Cfg2048(); if (err == hipSuccess) err = ensure_attrs_Cfg2048B(); if (err == hipSuccess) err = ensure_attrs_Cfg2048P(); break;
         case 4096: err = ensure_attrs_Cfg4096(); if (err == hipSuccess) err = ensure_attrs_Cfg4096B(); break;
         case 8192: err = ensure_attrs_Cfg8192(); break;
@@ -314,8 +322,17 @@ static bool wants_plan_pair(int n, const jsg_stft_args* g, int n_cu, bool displa
     return b_plan_fills_its_rounds(frames_of_launch >= 0 ? frames_of_launch : g->n_frames, Cfg2048P::TPB, n_cu);
 }
 
-// 2048 / 4096 points: does this launch take the "B" kernel?  (nc: channels combined into one column)
+// 1024 points (round 6): the two-stage plan Cfg1024B -- float columns, sum-type and one-channel mixes.  plan_select = 2 pins it where it
+// applies; the automatic rule (k1024BByDefault) is what the A/B on the C2 dispatch decided.
+constexpr bool k1024BByDefault = false;
+// 1024 / 2048 / 4096 points: does this launch take the "B" kernel?  (nc: channels combined into one column)
 static bool wants_plan_b(int n, const jsg_stft_args* g, int nc, int n_cu, long long frames_of_launch = -1) {   // (-1: g->n_frames)
+    if (n == 1024) {
+        if (g->mix_mode == JSG_MIX_MAX || g->mix_mode == JSG_MIX_MIN) return false;
+        if (g->plan_select == 2) return true;
+        if (g->plan_select != 0 || !k1024BByDefault) return false;
+        return b_plan_fills_its_rounds(frames_of_launch >= 0 ? frames_of_launch : g->n_frames, Cfg1024B::TPB, n_cu);
+    }
     if (n != 2048 && n != 4096) return false;
     static const int forced2048 = dev_knob_int("JSG_2048_PLAN");   // variant builds only (JSG_DEV_KNOBS): 2 = "B" | 3
     static const int forced4096 = dev_knob_int("JSG_4096_PLAN");
@@ -442,14 +459,15 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     // (a strided launch is judged by the frames of ALL its rows: the "B" kernels then fill their rounds)
     const bool plan_p = wants_plan_pair(plan->n, g, n_cu, io != nullptr, bs ? rows * g->n_frames : -1) && mixop == 0 && !ka.per_channel &&
                         ((ka.c_end - ka.c_begin) & 1) == 0;
-    const bool plan_b = !plan_p && ((io && io->argb && plan->n == 4096) ||
-                        wants_plan_b(plan->n, g, ka.per_channel ? 1 : ka.c_end - ka.c_begin, n_cu, bs ? rows * g->n_frames : -1));
+    const bool plan_b = !plan_p && !(plan->n == 1024 && io) &&   // (1024 points: the display launches keep the three-stage plans)
+                        ((io && io->argb && plan->n == 4096) ||
+                         wants_plan_b(plan->n, g, ka.per_channel ? 1 : ka.c_end - ka.c_begin, n_cu, bs ? rows * g->n_frames : -1));
     if (plan_b) ka.tab = plan->d_tab_b;
     if (plan_p) ka.tab = plan->d_tab_p;
     int tpb = 0;
     switch (plan->n) {
         case 512: tpb = Cfg512::TPB; break;
-        case 1024: tpb = (io && io->argb) ? Cfg1024I::TPB : Cfg1024::TPB; break;   // (the display path's eight-column workgroups)
+        case 1024: tpb = (io && io->argb) ? Cfg1024I::TPB : plan_b ? Cfg1024B::TPB : Cfg1024::TPB; break;   // (the display path's eight-column workgroups)
         case 2048: tpb = plan_p ? Cfg2048P::TPB : plan_b ? Cfg2048B::TPB : Cfg2048::TPB; break;
         case 4096: tpb = plan_b ? Cfg4096B::TPB : Cfg4096::TPB; break;
         case 8192: tpb = Cfg8192::TPB; break;
@@ -513,7 +531,7 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     if (bs) {
         switch (plan->n) {
             case 512: err = launch_strided_Cfg512(ka, mixop, grid, s); break;
-            case 1024: err = launch_strided_Cfg1024(ka, mixop, grid, s); break;
+            case 1024: err = plan_b ? launch_strided_Cfg1024B(ka, mixop, grid, s) : launch_strided_Cfg1024(ka, mixop, grid, s); break;
             case 2048: err = plan_p ? launch_strided_Cfg2048P(ka, mixop, grid, s) : plan_b ? launch_strided_Cfg2048B(ka, mixop, grid, s) : launch_strided_Cfg2048(ka, mixop, grid, s); break;
             case 4096: err = plan_b ? launch_strided_Cfg4096B(ka, mixop, grid, s) : launch_strided_Cfg4096(ka, mixop, grid, s); break;
             case 8192: err = launch_strided_Cfg8192(ka, mixop, grid, s); break;
@@ -523,7 +541,7 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     }
     switch (plan->n) {
         case 512: err = launch_Cfg512(ka, mixop, grid, s); break;
-        case 1024: err = (io && io->argb) ? launch_Cfg1024I(ka, mixop, grid, s) : launch_Cfg1024(ka, mixop, grid, s); break;
+        case 1024: err = (io && io->argb) ? launch_Cfg1024I(ka, mixop, grid, s) : plan_b ? launch_Cfg1024B(ka, mixop, grid, s) : launch_Cfg1024(ka, mixop, grid, s); break;
         case 2048: err = plan_p ? launch_Cfg2048P(ka, mixop, grid, s) : plan_b ? launch_Cfg2048B(ka, mixop, grid, s) : launch_Cfg2048(ka, mixop, grid, s); break;
         case 4096: err = plan_b ? launch_Cfg4096B(ka, mixop, grid, s) : launch_Cfg4096(ka, mixop, grid, s); break;
         case 8192: err = launch_Cfg8192(ka, mixop, grid, s); break;

@@ -1,4 +1,4 @@
-// Translation unit A of the STFT kernels: the 512-, 1024-, 2048- (three kernels) and 8192-point plans.
+// Translation unit A of the STFT kernels: the 512-, 1024- (three kernels), 2048- (three kernels) and 8192-point plans.
 // Compiled with -mllvm -amdgpu-sched-strategy=max-ilp (jadespectrogram_amd/_build.py): the ILP-first machine scheduler keeps
 // dependent packed-math instructions apart (a consumer directly behind its v_pk_*_f32 producer is given an s_nop by the hazard
 // recognizer: 264 of them in the two-stage 2048-point kernel, 69 with this scheduler) and needs fewer s_waitcnt.  Measured
@@ -10,6 +10,7 @@ namespace jsg {
 JSG_DEFINE_PLAN(Cfg512)
 JSG_DEFINE_PLAN(Cfg1024)
 JSG_DEFINE_PLAN(Cfg1024I)
+JSG_DEFINE_PLAN(Cfg1024B)
 JSG_DEFINE_PLAN(Cfg2048)
 JSG_DEFINE_PLAN(Cfg2048B)
 JSG_DEFINE_PLAN(Cfg2048P)

@@ -453,7 +453,10 @@ struct Cfg {
     static constexpr int e1max = (R1 - 1) * S1 + M / R1;
     static constexpr int e2max = TWO_STAGE ? 0 : (R1 - 1) * AX + (R2 - 1) * AY + (R3 - 1) * AZ + 1;
     static constexpr int raw = e1max > e2max ? (e1max > M + 1 ? e1max : M + 1) : (e2max > M + 1 ? e2max : M + 1);
-    static constexpr int LDS_ELEMS = (raw + 1) & ~1;  // float2 elements per frame slot, 16-byte multiple
+    // float2 elements per frame slot, 16-byte multiple.  L = 16 (four frames side by side in a wavefront): an 8-byte LDS access is served 32
+    // lanes at a time, i.e. the 128-byte runs of TWO neighbouring frames together -- their regions start 128 bytes apart modulo the 256 bytes
+    // of the 64 banks (LDS_ELEMS == 16 mod 32), so that the two runs fall into different halves of the banks.
+    static constexpr int LDS_ELEMS = L_ == 16 ? (raw - 16 + 31) / 32 * 32 + 16 : (raw + 1) & ~1;
     static constexpr int LDS_BYTES = LDS_ELEMS * SLOTS * 8;                        // dynamic: exchange buffers
     static constexpr int LDS_TOTAL = LDS_BYTES + (TLOC == 1 ? TAB_ELEMS : 2) * 8;  // + static: lane tables
     static_assert(R1 * R2 * R3 == M, "radices");
@@ -482,6 +485,14 @@ using Cfg1024 = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 4, 1, 6, 1, 0, 0, 0, 1>;   
 // ... and the eight-wave form for the single-kernel display path (OUTK == 2), whose store phase is laid out for eight columns per step;
 // same tables, same arithmetic per frame (bit-identical columns); instantiated for that path only (image_only)
 using Cfg1024I = Cfg<1024, 8, 8, 8, 64, 72, 9, 72, 2, 8, 1, 6>;
+// 1024 points as TWO stages with ONE exchange (round 6): 512 complex points = split-radix 16 x 32, the engine of Cfg2048B.
+// 16 lanes per frame, 32 complex values per lane, FOUR frames side by side in a wavefront, one 8-wave workgroup (32 frames per step) per CU:
+// 32 x 4.4 KB of exchange + 10.5 KB of tables.  Against the three-stage plan per frame: one exchange of 32 writes + 16 16-byte reads per four
+// frames instead of two of 8 + 8 per frame, the lane tables read once per four frames, 2 x 80 + 212 packed instructions of butterflies per four
+// frames... (tools/kernel_regs.py and the PMC figures in DESIGN.md section 6).  A 4 x 4 transposition across the quarter-waves
+// (v_permlane32_swap + v_permlane16_swap) turns the registers into runs of 64 consecutive bins of ONE frame before the column stores.
+// dB / power columns only (sum-type and one-channel mixes); opt-in or automatic: see wants_plan_1024b in jsg_kernels.hip.
+using Cfg1024B = Cfg<1024, 16, 32, 1, 16, 34, 0, 0, 0, 8, 1, 1>;
 // factorised stage-2 / post tables (Cfg::TWF): 11.3 instead of 21.2 KB of tables, so that THREE 4-wave workgroups fit a CU (12 waves
 // instead of 8): stereo launches -9..-13 %, mono -1..-5 %
 using Cfg2048 = Cfg<2048, 16, 8, 8, 64, 72, 65, 16, 2, 4, 1, 3, 1, 1, 1>;   // (6-, 8-, 12-wave workgroups: no faster)
@@ -1299,6 +1310,9 @@ __global__ __launch_bounds__(C::WPB * 64, (JSG_RTAB_OF(C, MIXOP, OUTK) ? 5 : C::
                         const int ay = __builtin_amdgcn_readlane(__float_as_int(z.y), 0), by = __builtin_amdgcn_readlane(__float_as_int(z.y), 32);
                         z.x = __int_as_float(sub ? bx : ax);
                         z.y = __int_as_float(sub ? by : ay);
+                    } else if constexpr (L == 16) {   // lane 0 of every row of 16 lanes to its row: DPP row_newbcast:0
+                        z.x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(z.x), 0x150, 0xf, 0xf, false));
+                        z.y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(z.y), 0x150, 0xf, 0xf, false));
                     }
                     // (the fused form is written out: which of the two products the compiler contracts is its choice otherwise, and
                     // oracle/jsg_mirror.c restates this kernel operation by operation)
@@ -1430,6 +1444,29 @@ __global__ __launch_bounds__(C::WPB * 64, (JSG_RTAB_OF(C, MIXOP, OUTK) ? 5 : C::
                         const auto hi = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[f][m].y), __float_as_uint(acc[f][m + 1].y), false, false);
                         acc[f][m] = cf{__uint_as_float(lo[0]), __uint_as_float(hi[0])};
                         acc[f][m + 1] = cf{__uint_as_float(lo[1]), __uint_as_float(hi[1])};
+                    }
+                }
+                if constexpr (L == 16) {
+                    // FOUR frames side by side (quarter-wave s = lanes 16 s .. 16 s + 15), register rho of a lane = bin ll + 16 rho of ITS frame.
+                    // A 4 x 4 transposition of (register within a group of four) x (quarter-wave): v_permlane32_swap trades the upper half of
+                    // register a against the lower half of register c (and b against d), v_permlane16_swap then the odd quarters of a against
+                    // the even quarters of b (and c against d) -- afterwards register 4 q + j holds bins 64 q + lane of frame j over all 64
+                    // lanes (.x; .y: the mirrored bins M - those): 256 contiguous bytes of one column per store instruction.
+                    static_assert(L != 16 || (P / 2) % 4 == 0, "groups of four registers");
+                    auto tr4 = [](float& r0, float& r1, float& r2, float& r3) {
+                        const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(r0), __float_as_uint(r2), false, false);
+                        const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(r1), __float_as_uint(r3), false, false);
+                        const auto t01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+                        const auto t23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+                        r0 = __uint_as_float(t01[0]); r1 = __uint_as_float(t01[1]); r2 = __uint_as_float(t23[0]); r3 = __uint_as_float(t23[1]);
+                    };
+#pragma unroll
+                    for (int m = 0; m < P / 2; m += 4) {
+                        float lo0 = acc[f][m].x, lo1 = acc[f][m + 1].x, lo2 = acc[f][m + 2].x, lo3 = acc[f][m + 3].x;
+                        float up0 = acc[f][m].y, up1 = acc[f][m + 1].y, up2 = acc[f][m + 2].y, up3 = acc[f][m + 3].y;
+                        tr4(lo0, lo1, lo2, lo3);
+                        tr4(up0, up1, up2, up3);
+                        acc[f][m] = cf{lo0, up0}; acc[f][m + 1] = cf{lo1, up1}; acc[f][m + 2] = cf{lo2, up2}; acc[f][m + 3] = cf{lo3, up3};
                     }
                 }
                 // column of the frame whose bins register rho holds after the swap (L == 32), else this lane's own
@@ -1576,6 +1613,33 @@ __global__ __launch_bounds__(C::WPB * 64, (JSG_RTAB_OF(C, MIXOP, OUTK) ? 5 : C::
                         }
                         tl_row = a.tail + (long long)trow * a.ring_w;
                     }
+                    if constexpr (L == 16) {
+                        // as the L <= 64 form below with four frames: register 4 q + j = window q (bins 64 q + lane and their mirror) of frame j
+                        static_assert(L != 16 || OUTK == 0, "the 16-lane plan writes float columns");
+                        float* dJ[4];
+                        unsigned cJ[4];
+                        float nyJ[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            cJ[j] = (unsigned)__builtin_amdgcn_readlane((int)col, 16 * j);
+                            dJ[j] = a.out + (long long)cJ[j] * a.out_pitch + cofs;
+                            nyJ[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(accNy[f]), 16 * j));
+                        }
+                        const int lu = lane == 0 ? 64 : lane;
+#pragma unroll
+                        for (int rho = 0; rho < P / 2; ++rho) {
+                            const int j = rho % 4, q = rho / 4;
+                            float* d = dJ[j];
+                            __builtin_nontemporal_store(acc[f][rho].x, &d[lane + 64 * q]);
+                            const float nxt = rho + 4 < P / 2 ? acc[f][rho + 4].y : nyJ[j];
+                            const float up = lane == 0 ? nxt : acc[f][rho].y;
+                            __builtin_nontemporal_store(up, &d[M - (lu + 64 * q)]);
+                            if (q == 0 && lane == 0) {                      // bin M
+                                if (tl_row) tl_row[cJ[j]] = acc[f][rho].y;
+                                else __builtin_nontemporal_store(acc[f][rho].y, &d[M]);
+                            }
+                        }
+                    } else
                     if constexpr (L <= 64) {
                         // Whole 128-byte lines.  The lower half of the column (bins k = lane + 64 r) starts every instruction on a line.  The
                         // upper half is the mirror, bins M - k: as the registers hold them an instruction would cover bins M - 64 r - 63 ..
@@ -1728,9 +1792,20 @@ constexpr bool image_ok = C::L == 64 && C::FPW == 1 && C::TPB == 8 && C::WPB == 
 template <class C>
 constexpr bool image_only = std::is_same<C, Cfg1024I>::value;
 
+// plans that exist for float columns (dB / power) and the sum-type and one-channel mixes only: the 16-lane two-stage plan
+template <class C>
+constexpr bool db_only = C::L == 16;
+
 // every instantiation of a plan that can be launched: (MIXOP, OUTK, STREAM) x the two logarithms
 template <class C, int XLOG>
 hipError_t ensure_lds_attrs_of_plan_x() {
+    if constexpr (db_only<C>) {
+        hipError_t e = ensure_lds_attr<C, 0, 0, 0, XLOG>();
+        if (e == hipSuccess) e = ensure_lds_attr<C, 3, 0, 0, XLOG>();
+        if (e == hipSuccess) e = ensure_lds_attr<C, 0, 0, 1, XLOG>();
+        if (e == hipSuccess) e = ensure_lds_attr<C, 3, 0, 1, XLOG>();
+        return e;
+    } else
     if constexpr (C::PAIR) {   // the pair plan exists for the sum-type mixes and float columns only
         hipError_t e = ensure_lds_attr<C, 0, 0, 0, XLOG>();
         if (e == hipSuccess) e = ensure_lds_attr<C, 0, 0, 1, XLOG>();
@@ -1781,6 +1856,10 @@ hipError_t launch_stft_mix(const StftKArgs& ka, dim3 grid, hipStream_t s) {
 
 template <class C>
 hipError_t launch_stft(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s) {
+    if constexpr (db_only<C>) {
+        if (ka.argb || ka.idx || (mixop != 0 && mixop != 3)) return hipErrorInvalidValue;
+        return mixop == 3 ? launch_stft_mix<C, 3>(ka, grid, s) : launch_stft_mix<C, 0>(ka, grid, s);
+    } else
     if constexpr (C::PAIR) {
         if (ka.argb || ka.idx || mixop != 0) return hipErrorInvalidValue;
         return launch_stft_mix<C, 0>(ka, grid, s);
@@ -1829,7 +1908,7 @@ hipError_t launch_stft_strided(const StftKArgs& ka, int mixop, dim3 grid, hipStr
 // jsg_stft_b.hip: JSG_STFT_PLANS below); jsg_kernels.hip reaches them through these plain functions only, so no kernel is
 // ever compiled twice and hipFuncSetAttribute always addresses the one copy that is launched.
 // ------------------------------------------------------------------------------------------------------------
-#define JSG_FOR_EACH_PLAN(X) X(Cfg512) X(Cfg1024) X(Cfg1024I) X(Cfg2048) X(Cfg2048B) X(Cfg2048P) X(Cfg4096) X(Cfg4096B) X(Cfg8192)
+#define JSG_FOR_EACH_PLAN(X) X(Cfg512) X(Cfg1024) X(Cfg1024I) X(Cfg1024B) X(Cfg2048) X(Cfg2048B) X(Cfg2048P) X(Cfg4096) X(Cfg4096B) X(Cfg8192)
 #define JSG_DECLARE_PLAN(C)                                                                   \
     hipError_t launch_##C(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s);          \
     hipError_t launch_strided_##C(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s);  \

@@ -167,7 +167,8 @@ static void sr_dft_win(int R, cf* x, const cf* w) {
 
 typedef struct { const char* name; int N, R1, R2, R3, L, twf; } mplan;
 static const mplan kPlans[] = {   /* jsg_stft_kernel.h: Cfg512 .. Cfg8192 (radices, lanes per frame, factorised tables) */
-    {"Cfg512", 512, 8, 8, 4, 32, 0},     {"Cfg1024", 1024, 8, 8, 8, 64, 0},    {"Cfg2048", 2048, 16, 8, 8, 64, 1}, {"Cfg2048B", 2048, 32, 32, 1, 32, 0},
+    {"Cfg512", 512, 8, 8, 4, 32, 0},     {"Cfg1024", 1024, 8, 8, 8, 64, 0},    {"Cfg1024B", 1024, 16, 32, 1, 16, 0},
+    {"Cfg2048", 2048, 16, 8, 8, 64, 1}, {"Cfg2048B", 2048, 32, 32, 1, 32, 0},
     {"Cfg4096", 4096, 16, 8, 16, 128, 0}, {"Cfg4096B", 4096, 8, 16, 16, 64, 1}, {"Cfg8192", 8192, 16, 16, 16, 256, 1}};
 
 static const double two_pi = 6.283185307179586476925286766559;

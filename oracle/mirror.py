@@ -7,7 +7,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libjsg_mirror.so")
-PLANS = {512: ("Cfg512",), 1024: ("Cfg1024",), 2048: ("Cfg2048", "Cfg2048B", "Cfg2048P"), 4096: ("Cfg4096", "Cfg4096B"), 8192: ("Cfg8192",)}
+PLANS = {512: ("Cfg512",), 1024: ("Cfg1024", "Cfg1024B"), 2048: ("Cfg2048", "Cfg2048B", "Cfg2048P"), 4096: ("Cfg4096", "Cfg4096B"), 8192: ("Cfg8192",)}
 
 
 class _Mirror:

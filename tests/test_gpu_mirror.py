@@ -45,6 +45,10 @@ CASES = [  # (n, plan_select, kernel name, channels, hop, feedblocks, mix, windo
     (1024, 0, "Cfg1024", 3, 256, 4, "absmean", 2, "synth"), (1024, 0, "Cfg1024", 5, 102, 10, "max", 4, "noise"),
     (1024, 0, "Cfg1024", 4, 1024, 1, "min", 0, "synth"), (1024, 0, "Cfg1024", 2, 512, 2, "right", 5, "sparse"),
     (1024, 0, "Cfg1024", 8, 512, 2, "sum", 1, "quiet"),
+    # round 6: the two-stage 1024-point plan (split-radix 16 x 32, 16 lanes per frame, four frames per wavefront; plan_select = 2)
+    (1024, 2, "Cfg1024B", 1, 512, 2, "absmean", 1, "synth"), (1024, 2, "Cfg1024B", 2, 512, 2, "absmean", 1, "noise"),
+    (1024, 2, "Cfg1024B", 3, 256, 4, "absmean", 2, "synth"), (1024, 2, "Cfg1024B", 8, 512, 2, "sum", 1, "quiet"),
+    (1024, 2, "Cfg1024B", 2, 512, 2, "right", 5, "sparse"), (1024, 2, "Cfg1024B", 5, 102, 10, "absmean", 4, "noise"),
     (2048, 1, "Cfg2048", 1, 1024, 2, "absmean", 1, "synth"), (2048, 1, "Cfg2048", 8, 512, 4, "absmean", 1, "noise"),
     (2048, 2, "Cfg2048B", 8, 512, 4, "absmean", 1, "synth"), (2048, 2, "Cfg2048B", 1, 1024, 2, "absmean", 3, "sparse"), (2048, 2, "Cfg2048B", 3, 205, 1, "absmean", 2, "noise"),
     (4096, 1, "Cfg4096", 2, 512, 8, "absmean", 1, "synth"), (4096, 1, "Cfg4096", 1, 2048, 2, "left", 4, "noise"),
