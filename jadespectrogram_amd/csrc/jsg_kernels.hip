@@ -323,14 +323,17 @@ static bool wants_plan_pair(int n, const jsg_stft_args* g, int n_cu, bool displa
 }
 
 // 1024 points (round 6): the two-stage plan Cfg1024B -- float columns, sum-type and one-channel mixes.  plan_select = 2 pins it where it
-// applies; the automatic rule (k1024BByDefault) is what the A/B on the C2 dispatch decided.
-constexpr bool k1024BByDefault = false;
+// applies, 1 pins the three-stage plan.  Automatic rule = what the interleaved A/B decided (tools/plan1024b_ab.py):
+// one channel per column (C2, the C4 shard) it is 3-7 % BEHIND the three-stage plan (two waves per SIMD instead of five; its core clock under
+// the 1400 W cap is 2.0-2.1 instead of 1.6 GHz and it is still slower), two channels mixed +1.5 %, four +3.3 %, eight +4.1..+4.8 %: taken
+// from four channels per column on, for launches that fill their rounds of one workgroup per CU.
+constexpr int k1024B_min_channels = 4;
 // 1024 / 2048 / 4096 points: does this launch take the "B" kernel?  (nc: channels combined into one column)
 static bool wants_plan_b(int n, const jsg_stft_args* g, int nc, int n_cu, long long frames_of_launch = -1) {   // (-1: g->n_frames)
     if (n == 1024) {
         if (g->mix_mode == JSG_MIX_MAX || g->mix_mode == JSG_MIX_MIN) return false;
         if (g->plan_select == 2) return true;
-        if (g->plan_select != 0 || !k1024BByDefault) return false;
+        if (g->plan_select != 0 || nc < k1024B_min_channels) return false;
         return b_plan_fills_its_rounds(frames_of_launch >= 0 ? frames_of_launch : g->n_frames, Cfg1024B::TPB, n_cu);
     }
     if (n != 2048 && n != 4096) return false;

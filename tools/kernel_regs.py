@@ -70,7 +70,7 @@ def main():
                       f"scratch {g('private_segment_fixed_size'):>3} lds {g('group_segment_fixed_size'):>6} | static: valu {valu} (pk {pk}) ds {lds} vmem {vmem} "
                       f"nop {mx.get('s_nop', 0)} mov {mx.get('v_mov_b32_e32', 0) + mx.get('v_mov_b32_e64', 0)} swap {mx.get('v_permlane32_swap_b32_e32', 0)}")
                 if isa_pat and re.search(isa_pat, short(name)):
-                    print(dis.split(f"<{name}>:")[1].split("\n\n")[0][:200000])
+                    print(dis.split(f"<{name}>:")[1].split("\n\n")[0][:2000000])
 
 
 if __name__ == "__main__":

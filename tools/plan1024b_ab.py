@@ -19,7 +19,8 @@ hop = int(os.environ.get("AB_HOP", "512")); C = int(os.environ.get("AB_CHANNELS"
 mixname = os.environ.get("AB_MIX", "absmean")
 per_ch = mixname == "per_channel"
 mix = jsg.capi.MIX_PER_CHANNEL if per_ch else jsg.capi.MIX_ABSMEAN
-rounds = int(os.environ.get("AB_ROUNDS", "7")); reps = int(os.environ.get("AB_REPS", "2400"))   # ~0.5 s per leg: long enough for the 50 ms telemetry samples; use_tail = os.environ.get("AB_TAIL") == "1"
+rounds = int(os.environ.get("AB_ROUNDS", "7")); reps = int(os.environ.get("AB_REPS", "2400"))   # ~0.5 s per leg: long enough for the 50 ms telemetry samples
+use_tail = os.environ.get("AB_TAIL") == "1"
 M, H = n // 2, n // 2 + 1
 pitch = M if use_tail else (H + 31) // 32 * 32
 plan = jsg.Plan(n, jsg.window(jsg.capi.WIN_HANN, n))
