@@ -146,7 +146,12 @@ typedef struct jsg_stft_args {
                                 launches run concurrently, worse for one launch alone */
     int64_t in_samples;      /* floats of every channel row that may be read; the launch is refused (JSG_ERR_INVALID) when
                                 its last frame would read past them.  0: unknown, not checked */
-    int32_t plan_select;     /* 2048 / 4096 points have two kernels each.  0: automatic -- the large-workgroup "B" kernel (one 8-wave
+    int32_t plan_select;     /* 1024 points (round 6): 0 automatic -- the two-stage kernel "Cfg1024B" (split-radix 16 x 32, four frames
+                                per wavefront, one 8-wave workgroup of 32 columns per CU) where >= 4 channels are mixed into one column
+                                (AbsMean / Sum) and the launch fills its rounds, the three-stage kernel "Cfg1024" otherwise; 1: always
+                                "Cfg1024" (the engine pins this); 2: "Cfg1024B" wherever it exists (float columns, not Max / Min, not the
+                                display launches).  The two agree inside the float32 bound, not bit for bit.
+                                2048 / 4096 points have two kernels each.  0: automatic -- the large-workgroup "B" kernel (one 8-wave
                                 workgroup of 16 / 8 columns per CU; faster when it can fill the GPU) for launches that fill their
                                 rounds of <CU count> workgroups to at least 87 % (e.g. 3584..4096 columns of 2048 points or
                                 1784..2048 of 4096 points on 256 CUs, or any launch of 7 rounds and more) AND, at 2048 points, mix

@@ -386,7 +386,7 @@ def _stft_args(plan: Plan, d_in, hop: int, n_frames: int, d_out, *, feedblocks: 
     a.blocks_per_cu = int(blocks_per_cu)
     a.exact_log = int(bool(exact_log))     # dB by the shared float32 routine (bit-reproducible on a CPU) instead of v_log_f32
     a.plan_select = int(plan_select)       # 0 automatic, 1 small-workgroup kernel, 2 "B" kernel (2048 / 4096 points), 3 pair plan (2048 points, even channel
-                                           # counts, sum-type mixes), 4 two-stage kernel (1024 points; include/jsg.h)
+                                           # counts, sum-type mixes); 1024 points: 2 = the two-stage kernel Cfg1024B (include/jsg.h)
     if d_tail is not None:
         assert d_tail.is_cuda and d_tail.dtype == torch.float32 and d_tail.is_contiguous() and d_tail.shape[-1] == d_out.shape[-2]
         a.out_tail = d_tail.data_ptr()
