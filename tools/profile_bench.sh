@@ -6,7 +6,7 @@
 #   3. one SQ counter pass
 # Summaries are post-processed by tools/profile_summarize.py into gpurun_out/profiles_<tag>/ (copy them to profiles/).
 set -u
-TAG=${1:-r04}; CFG=${2:-c2}
+TAG=${1:-r06}; CFG=${2:-c2}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_bench_${TAG}_${CFG}
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
