@@ -576,9 +576,15 @@ def main():
         dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(dev_index)
     red_dev = "cuda" if backend == "nccl" else "cpu"
-    if world > 1:
+    # JSG_BENCH_DIST_SINGLE=1: a ONE-rank process group on the real backend (RCCL on the GPU box) -- rehearses exactly the calls the N > 1 runs
+    # make (init with device_id, barrier, max-reduction of a CUDA tensor, destroy) where only one GPU is there (tests/test_bench_cli.py)
+    if world > 1 or os.environ.get("JSG_BENCH_DIST_SINGLE") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+            os.environ.setdefault("MASTER_PORT", str(port)); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:

@@ -827,6 +827,17 @@ __global__ __launch_bounds__(C::WPB * 64, (JSG_RTAB_OF(C, MIXOP, OUTK) ? 5 : C::
         in_off = (long long)batch * a.in_image_stride + (long long)ch * a.in_pitch;
         out_off = (long long)batch * a.out_batch_stride + (long long)ch * a.out_cpitch;
     };
+    // CARRY (round 6; strided one-channel kernels): a round's row, first column and ring offset are computed ONCE, when its loads are issued
+    // (frame_src, one round ahead), and carried in scalar registers to its epilogue a round later -- which used to recompute group_of / row_of
+    // (two 64-bit magic multiplies, the batch and channel offsets): 156 scalar instructions per frame in the loop of the C2 kernel against 67 in
+    // the single-batch kernel.  Same values, same bits.
+#ifdef JSG_X_NO_CARRY   // (variant builds: the rounds 4-5 form, for A/B)
+    constexpr bool CARRY = false;
+#else
+    constexpr bool CARRY = BAT && MIXOP == 3 && !C::PAIR && F == 1;
+#endif
+    unsigned nx_row = 0, nx_col0 = 0, cu_row = 0, cu_col0 = 0;   // nx_*: of the round whose loads were issued last; cu_*: of the round being transformed
+    long long nx_out = 0, cu_out = 0;
     auto task_of = [&](unsigned it, int f) -> unsigned {
         unsigned t;
         if constexpr (OUTK == 2 || BAT) {
@@ -858,6 +869,7 @@ __global__ __launch_bounds__(C::WPB * 64, (JSG_RTAB_OF(C, MIXOP, OUTK) ? 5 : C::
             group_of(it, row, col0);
             row_of(row, in_off, out_off);
             start += in_off;
+            if constexpr (CARRY) { nx_row = row; nx_col0 = col0; nx_out = out_off; }
         }
         if constexpr (C::PAIR)   // the lane's samples of BOTH channels: x_c[start + 64 m + 2 ll + h] (see frame_load)
             return reinterpret_cast<const f2u*>(a.in + (long long)c * a.in_pitch + start + (2 * ll + sub));
@@ -1009,6 +1021,7 @@ __global__ __launch_bounds__(C::WPB * 64, (JSG_RTAB_OF(C, MIXOP, OUTK) ? 5 : C::
     // independent chains, and each table value is fetched once for all of them.
     auto process = [&](int s, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
+        if constexpr (CARRY) { cu_row = nx_row; cu_col0 = nx_col0; cu_out = nx_out; }   // (before the prefetch below overwrites nx_*)
         cf x[F][P];
         JSG_MARK(0);
         // ---- window multiply: register m = u + U1 n1 is input n1 of stage-1 butterfly u.  The upper inputs (n1 >= R1 / 2) are multiplied
@@ -1403,7 +1416,12 @@ __global__ __launch_bounds__(C::WPB * 64, (JSG_RTAB_OF(C, MIXOP, OUTK) ? 5 : C::
             }
 #pragma unroll
             for (int f = 0; f < F; ++f) {
-                unsigned col = a.ring_pos + task_of(it, f);        // n_frames <= ring_w (checked by the launcher)
+                unsigned tk;
+                if constexpr (CARRY) {
+                    tk = cu_col0 + slot0 + tsub * F + f;
+                    tk = tk < a.n_frames ? tk : a.n_frames - 1;
+                } else tk = task_of(it, f);
+                unsigned col = a.ring_pos + tk;                    // n_frames <= ring_w (checked by the launcher)
                 if (col >= (unsigned)a.ring_w) col -= a.ring_w;
                 const bool fuse_scale = !ONE && !XLOG && !a.linear && !a.exact_div;   // (uniform) v_log path of a mixing kernel: see below
                 if constexpr (ONE) {
@@ -1601,7 +1619,8 @@ __global__ __launch_bounds__(C::WPB * 64, (JSG_RTAB_OF(C, MIXOP, OUTK) ? 5 : C::
                     // non-temporal dword stores, 256 contiguous bytes of the column per instruction (streaming the columns out
                     // instead of leaving them dirty in L2 removed the end-of-kernel write-back)
                     long long cofs = a.per_channel ? (long long)c0 * a.out_cpitch : 0ll;
-                    if constexpr (BAT) {   // the ring of this row (batch, or batch and channel)
+                    if constexpr (CARRY) cofs = cu_out;
+                    else if constexpr (BAT) {   // the ring of this row (batch, or batch and channel)
                         unsigned row, col0_;
                         long long in_off;
                         group_of(it, row, col0_);
@@ -1615,7 +1634,8 @@ __global__ __launch_bounds__(C::WPB * 64, (JSG_RTAB_OF(C, MIXOP, OUTK) ? 5 : C::
                     float* tl_row = nullptr;
                     if (a.tail) {
                         unsigned trow = a.per_channel ? (unsigned)c0 : 0u;
-                        if constexpr (BAT) {
+                        if constexpr (CARRY) trow = cu_row;
+                        else if constexpr (BAT) {
                             unsigned col0_;
                             group_of(it, trow, col0_);
                         }

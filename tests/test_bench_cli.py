@@ -110,6 +110,15 @@ def test_two_ranks_default_to_configs3_and_run_the_per_channel_kernels():
 
 
 @pytest.mark.gpu
+def test_one_rank_process_group_on_rccl_runs_the_n_gt_1_calls():
+    """What the driver's 8-GPU run does through torch.distributed -- init_process_group("nccl", device_id=...), barriers, the max-over-ranks
+    all_reduce of a CUDA tensor, destroy -- executed with ONE rank on the one GPU of the test box (RCCL had never run under bench.py)."""
+    j = _run([sys.executable, "bench.py", "--config", "c4", "--steps", "2", "--warmup", "1", "--dispatches-per-step", "2", "--nbuf", "3", "--no-cpu-baseline",
+              "--no-calibration", "--no-boundary", "--no-parity", "--no-power", "--no-single"], env={"JSG_BENCH_DIST_SINGLE": "1"})
+    assert j["n_gpus"] == 1 and j["value"] > 1e7 and j["roofline"]["avg_dispatch_us"] > 0
+
+
+@pytest.mark.gpu
 def test_c4_shard_line_on_one_gpu():
     j = _run([sys.executable, "bench.py", "--config", "c4", "--steps", "2", "--warmup", "1", "--dispatches-per-step", "2", "--no-cpu-baseline", "--no-calibration",
               "--no-boundary"])
