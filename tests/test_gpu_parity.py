@@ -400,7 +400,7 @@ def _random_geometries(count, seed):
         hop = n // feedblocks if feedblocks != 10 else [51, 102, 205, 410, 819][[512, 1024, 2048, 4096, 8192].index(n)]
         frames = int(rng.integers(1, 70))
         extra = int(rng.integers(0, 4))
-        sel = int(rng.choice([0, 1, 2])) if n in (2048, 4096) else 0      # which of the two 2048- / 4096-point kernels
+        sel = int(rng.choice([0, 1, 2])) if n in (1024, 2048, 4096) else 0      # which of the two 1024- (round 6) / 2048- / 4096-point kernels
         out.append((n, channels, mix, feedblocks, hop, frames, extra, sel))
     return out
 

@@ -47,7 +47,7 @@ def _run_case(jsg, oracle, torch, n, C, F, K, hop, fb=None, mix=None, W=None, ri
         assert name == expect_kernel, (name, expect_kernel)
     # the single launches, pinned to the plan the whole strided launch takes (2048 / 4096 points: the rule looks at the total size)
     pin = 0
-    if n in (2048, 4096):
+    if n in (1024, 2048, 4096):
         pin = 2 if name.endswith("B") else 1
     for b in range(K):
         jsg.stft_db(plan, d_in[b], hop, F, ref[b], plan_select=pin, **kw)
@@ -205,5 +205,6 @@ def test_seeded_random_strided_db_batches(jsg, oracle, torch_cuda, seed):
         W = F + int(rng.integers(0, 50))
         pos = int(rng.integers(0, W))
         bpc = int(rng.choice([0, 0, 1, 3, 7]))
+        sel = int(rng.choice([0, 0, 2])) if n == 1024 else 0      # round 6: a third of the 1024-point cases pin the two-stage plan (where it exists)
         _run_case(jsg, oracle, torch_cuda, n, C, F, K, hop, fb=fb, mix=mix, W=W, ring_pos=pos, first_frame=int(rng.integers(0, 5)), blocks_per_cu=bpc,
-                  linear=bool(rng.integers(0, 4) == 0))
+                  linear=bool(rng.integers(0, 4) == 0), plan_select=sel)
