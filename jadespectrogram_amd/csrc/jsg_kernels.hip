@@ -467,10 +467,14 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
                          wants_plan_b(plan->n, g, ka.per_channel ? 1 : ka.c_end - ka.c_begin, n_cu, bs ? rows * g->n_frames : -1));
     if (plan_b) ka.tab = plan->d_tab_b;
     if (plan_p) ka.tab = plan->d_tab_p;
+    // "runs" (STREAM == 2, round 6): strided one-channel dB launches of the 1024-point three-stage plan at exactly 50 % overlap -- a wavefront
+    // transforms kRunLen consecutive columns and keeps the overlapped half of the raw frame in registers (see stft_db_kernel)
+    static const bool no_runs = dev_knob_set("JSG_NO_RUNS");   // (variant builds only)
+    const bool runs = bs && plan->n == 1024 && !plan_b && !io && mixop == 3 && ka.regular && 2 * g->hop == plan->n && !ka.chunked && !no_runs;
     int tpb = 0;
     switch (plan->n) {
         case 512: tpb = Cfg512::TPB; break;
-        case 1024: tpb = (io && io->argb) ? Cfg1024I::TPB : plan_b ? Cfg1024B::TPB : Cfg1024::TPB; break;   // (the display path's eight-column workgroups)
+        case 1024: tpb = (io && io->argb) ? Cfg1024I::TPB : plan_b ? Cfg1024B::TPB : runs ? Cfg1024::TPB * jsg::kRunLen : Cfg1024::TPB; break;   // (the display path's eight-column workgroups)
         case 2048: tpb = plan_p ? Cfg2048P::TPB : plan_b ? Cfg2048B::TPB : Cfg2048::TPB; break;
         case 4096: tpb = plan_b ? Cfg4096B::TPB : Cfg4096::TPB; break;
         case 8192: tpb = Cfg8192::TPB; break;
@@ -534,7 +538,7 @@ static int stft_launch_impl(const jsg_plan* plan, const jsg_stft_args* g, const 
     if (bs) {
         switch (plan->n) {
             case 512: err = launch_strided_Cfg512(ka, mixop, grid, s); break;
-            case 1024: err = plan_b ? launch_strided_Cfg1024B(ka, mixop, grid, s) : launch_strided_Cfg1024(ka, mixop, grid, s); break;
+            case 1024: err = plan_b ? launch_strided_Cfg1024B(ka, mixop, grid, s) : runs ? launch_runs_Cfg1024(ka, mixop, grid, s) : launch_strided_Cfg1024(ka, mixop, grid, s); break;
             case 2048: err = plan_p ? launch_strided_Cfg2048P(ka, mixop, grid, s) : plan_b ? launch_strided_Cfg2048B(ka, mixop, grid, s) : launch_strided_Cfg2048(ka, mixop, grid, s); break;
             case 4096: err = plan_b ? launch_strided_Cfg4096B(ka, mixop, grid, s) : launch_strided_Cfg4096(ka, mixop, grid, s); break;
             case 8192: err = launch_strided_Cfg8192(ka, mixop, grid, s); break;

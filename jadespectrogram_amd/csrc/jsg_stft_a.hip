@@ -15,6 +15,7 @@ JSG_DEFINE_PLAN(Cfg2048)
 JSG_DEFINE_PLAN(Cfg2048B)
 JSG_DEFINE_PLAN(Cfg2048P)
 JSG_DEFINE_PLAN(Cfg8192)
+hipError_t launch_runs_Cfg1024(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s) { return launch_stft_strided<Cfg1024, 2>(ka, mixop, grid, s); }
 hipError_t touch_module_a() {
     hipFuncAttributes fa;
     return hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&stft_db_kernel<Cfg1024, 3>));

@@ -375,6 +375,12 @@ struct PairFirstLayer {
     }
 };
 
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), written out (the rounds of a run, stft_db_kernel STREAM == 2)
+template <class Fn, int... Ts>
+__device__ __forceinline__ void for_each_t(Fn&& f, std::integer_sequence<int, Ts...>) {
+    (f(std::integral_constant<int, Ts>{}), ...);
+}
+
 // Lanes of one wavefront run in lock-step, so a wave-private LDS exchange needs no s_barrier; what it does need is
 // that the COMPILER keeps the stores ahead of the loads that other lanes of the same wave perform.
 __device__ __forceinline__ void wave_sync() {
@@ -403,6 +409,11 @@ __device__ __forceinline__ cf to_cf(const f2u& v) { return cf{v.x, v.y}; }
 //   frame -- one fold per COLUMN instead.  The N-point transform is split by decimation in time: the two half-waves of a wavefront (L = 32)
 //   transform the even and the odd samples (E, O: two N/2-point FFTs with the two-stage engine of Cfg2048B), a v_permlane32_swap brings
 //   E[k] and O[k] into one lane, and Z[k] = E[k] + W_N^k O[k], Z[k + N/2] = E[k] - W_N^k O[k].  See "pair plan" in the kernel.
+#ifndef JSG_X_RUNLEN
+#define JSG_X_RUNLEN 2       // (variant builds sweep this: 2 / 4 / 8 -- measured 2 >= 4 > none > 8)
+#endif
+constexpr int kRunLen = JSG_X_RUNLEN;   // STREAM == 2 ("runs"): consecutive columns a wavefront transforms one after the other (see stft_db_kernel)
+
 template <int N_, int R1_, int R2_, int R3_, int L_, int S1_, int AX_, int AY_, int AZ_, int WPB_, int TLOC_, int WPS_,
           int FPW_ = 1, int EARLY1_ = 0, int TWF_ = 0, int PAIR_ = 0, int RTAB_ = 0>
 struct Cfg {
@@ -721,7 +732,7 @@ template <class C, int MIXOP, int OUTK = 0, int STREAM = 0, int XLOG = 0>
 // (RTAB instantiations: five waves per SIMD -- what the plan's LDS allows -- instead of the plan's C::WPS, see Cfg::RTAB.  Strided dispatches
 // only: a single launch of one 4096-frame batch gives every wave ONE frame, and reading the tables into registers first costs it 1-1.5 %
 // -- 5.33 vs 5.25 us, tools/single_launch_probe.py.)
-#define JSG_RTAB_OF(C, MIXOP, OUTK) (C::RTAB && MIXOP == 3 && OUTK == 0 && STREAM == 1)
+#define JSG_RTAB_OF(C, MIXOP, OUTK) (C::RTAB && MIXOP == 3 && OUTK == 0 && STREAM != 0)
 __global__ __launch_bounds__(C::WPB * 64, (JSG_RTAB_OF(C, MIXOP, OUTK) ? 5 : C::WPS)) JSG_NO_LDS_MERGE void stft_db_kernel(
     // Everything the table and frame loads depend on sits in the first 16 dwords of the kernel arguments: with
     // -amdgpu-kernarg-preload-count=16 those arrive in SGPRs with the wave, so the loads are issued without waiting for a
@@ -741,7 +752,16 @@ __global__ __launch_bounds__(C::WPB * 64, (JSG_RTAB_OF(C, MIXOP, OUTK) ? 5 : C::
     __shared__ int s_lut[OUTK == 2 ? 256 : 1];
     static_assert(OUTK != 2 || (C::L == 64 && C::FPW == 1 && C::LDS_TOTAL + 1024 <= 160 * 1024), "single-kernel display path: one wavefront per frame");
     constexpr bool BAT = STREAM != 0;   // rows (batches, or batch x channel) numbered through the launch
-    static_assert(STREAM == 0 || STREAM == 1, "see above");
+    // STREAM == 2 (round 6, "runs"; 50 % overlap, one channel per column, one wavefront per frame): a wavefront transforms kRunLen CONSECUTIVE
+    // columns of a row one after the other, and the upper half of a frame's raw samples -- which IS the lower half of the next frame -- stays
+    // in its registers: from the second column of a run on, only the new hop is loaded (P/2 loads instead of P; the other half used to come
+    // from L1 / L2: every sample was loaded twice).  A workgroup step is a super-group of TPB * kRunLen consecutive columns (wave w: columns
+    // w * kRunLen + t, t = 0 .. kRunLen - 1).  The two halves trade roles from round to round (the registers of the consumed lower half take
+    // the next round's upper half), so the round loop is unrolled by two and nothing is copied.  Same arithmetic, same bits.
+    constexpr bool RUNS = STREAM == 2;
+    constexpr int RL = kRunLen;
+    static_assert(STREAM == 0 || STREAM == 1 || STREAM == 2, "see above");
+    static_assert(!RUNS || (MIXOP == 3 && OUTK == 0 && C::L == 64 && C::FPW == 1 && !C::PAIR && (RL & (RL - 1)) == 0 && RL % 2 == 0), "runs: one-channel dB kernels of the 64-lane plans");
     static_assert(!BAT || OUTK == 0, "strided multi-batch launches write dB / power columns");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int L = C::L, P = C::P, M = C::M, R1 = C::R1, R2 = C::R2, R3 = C::R3, F = C::FPW;
@@ -896,6 +916,28 @@ __global__ __launch_bounds__(C::WPB * 64, (JSG_RTAB_OF(C, MIXOP, OUTK) ? 5 : C::
             for (int m = 0; m < P; ++m) dst[m] = src[L * m];
         }
     };
+    // ---- runs (STREAM == 2): the wave's run of RL consecutive columns of one row ----
+    f2u rw[2][RUNS ? P / 2 : 1];          // the two halves of the raw frame; in round t of a run rw[t & 1] is the lower half, rw[(t & 1) ^ 1] the upper
+    unsigned rn_col0 = 0;                 // first column (inside its row) of this wave's current run
+    long long rn_in = 0;                  // input offset of the run's row
+    bool nx_live = true, cu_live = true;  // the round's column exists (columns past the end of a row are transformed on whatever the clamped
+                                          // loads bring and NOT stored; the other kernels repeat the row's last column instead)
+    // a new run: super-group `sg` of this workgroup -> row, first column of this wave's run, the row's input / ring offsets (scalar, once per RL rounds)
+    auto runs_group = [&](unsigned sg) {
+        unsigned g = lb + sg * nblk;
+        if (g >= a.n_groups) g -= a.n_groups;                     // surplus steps of the last round start over with the first groups
+        const unsigned row = (unsigned)(((unsigned long long)g * a.img_magic) >> 40);
+        rn_col0 = (g - row * a.img_gpi) * (unsigned)(C::TPB * RL) + (unsigned)(slot0 * RL);
+        row_of(row, rn_in, nx_out);
+        nx_row = row;
+    };
+    // where column tu of the run's row starts (a column past the row's end: its last column, so that every load stays inside the row)
+    auto runs_src = [&](unsigned tu) -> const f2u* {
+        nx_live = tu < a.n_frames;
+        nx_col0 = nx_live ? tu : a.n_frames - 1;
+        const long long start = (long long)(a.first_frame + nx_col0) * a.hop + rn_in + (long long)c0 * a.in_pitch;
+        return reinterpret_cast<const f2u*>(a.in + start) + ll;
+    };
     // ---- lane tables first: two 16-byte LDS-DMA pieces per thread bring the tables from L2 straight into LDS (wave-uniform
     //      base + lane * 16 bytes, no VGPR round trip).  They are issued AHEAD of the frame loads: every wave's FFT start is
     //      gated by the workgroup barrier behind the tables, so they are the latency-critical load (frame loads first, or
@@ -914,7 +956,15 @@ __global__ __launch_bounds__(C::WPB * 64, (JSG_RTAB_OF(C, MIXOP, OUTK) ? 5 : C::
     }
     // ---- issue the loads of the first FFT round (software pipeline, one round ahead) ----
     f2u raw[F][P];
-    {
+    if constexpr (RUNS) {   // round 0: the whole frame, lower half into rw[0], upper half into rw[1] (P loads, as the other kernels: the counted wait below)
+        runs_group(0u);
+        const f2u* src = runs_src(rn_col0);
+#pragma unroll
+        for (int m = 0; m < P / 2; ++m) rw[0][m] = src[L * m];
+#pragma unroll
+        for (int m = 0; m < P / 2; ++m) rw[1][m] = src[L * (m + P / 2)];
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
 #pragma unroll
         for (int f = 0; f < F; ++f) frame_load(raw[f], frame_src(0, f));
         __builtin_amdgcn_sched_barrier(0);
@@ -1019,9 +1069,12 @@ __global__ __launch_bounds__(C::WPB * 64, (JSG_RTAB_OF(C, MIXOP, OUTK) ? 5 : C::
     // the steady-state loop free of the "did the prefetch happen" merge (register moves and a full vmcnt(0)).
     // Every stage loops over the F frames INSIDE the stage, in one basic block: the scheduler interleaves the frames'
     // independent chains, and each table value is fetched once for all of them.
-    auto process = [&](int s, auto last_tag) {
+    auto process = [&](int s, auto last_tag, auto t_tag) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_tag)::value;
+        constexpr int T = decltype(t_tag)::value;       // runs: the round's place in its run (0 otherwise)
+        constexpr int PAR = T & 1;                       // runs: which of rw[0] / rw[1] holds the lower half of this round's frame
         if constexpr (CARRY) { cu_row = nx_row; cu_col0 = nx_col0; cu_out = nx_out; }   // (before the prefetch below overwrites nx_*)
+        if constexpr (RUNS) cu_live = nx_live;
         cf x[F][P];
         JSG_MARK(0);
         // ---- window multiply: register m = u + U1 n1 is input n1 of stage-1 butterfly u.  The upper inputs (n1 >= R1 / 2) are multiplied
@@ -1039,6 +1092,15 @@ __global__ __launch_bounds__(C::WPB * 64, (JSG_RTAB_OF(C, MIXOP, OUTK) ? 5 : C::
             static_assert((P / 2) % 2 == 0 || P == 2, "the window pairs do not straddle the halves");
 #pragma unroll
             for (int f = 0; f < F; ++f) {
+                if constexpr (RUNS) {
+                    if (m < P / 2) {
+                        x[f][m] = to_cf(rw[PAR][m]);
+                        x[f][m + 1] = to_cf(rw[PAR][m + 1]);
+                    } else {
+                        x[f][m] = to_cf(rw[PAR ^ 1][m - P / 2]) * w0;
+                        x[f][m + 1] = to_cf(rw[PAR ^ 1][m + 1 - P / 2]) * w1;
+                    }
+                } else
                 if (m < P / 2) {     // (m < P/2 <=> n1 < R1/2: P/2 = U1 * R1/2)
                     x[f][m] = to_cf(raw[f][m]);
                     x[f][m + 1] = to_cf(raw[f][m + 1]);
@@ -1087,6 +1149,24 @@ __global__ __launch_bounds__(C::WPB * 64, (JSG_RTAB_OF(C, MIXOP, OUTK) ? 5 : C::
         // the wave's issue until the first has returned, a full memory round trip per FFT round.  The first half goes out here, the second
         // behind stage 1, when part of the first has arrived.)
         const f2u* next_src = nullptr;
+        if constexpr (RUNS) {
+            // the next round.  Inside a run only the NEW hop -- the upper half of the next frame -- is loaded, into the registers of this round's
+            // lower half (consumed by the time the data arrives); this round's upper half stays where it is and IS the next round's lower half.
+            // The last round of a run loads the whole first frame of the workgroup's next super-group.  Which of the two is a compile-time fact.
+            if constexpr (T + 1 < RL) {
+                const f2u* src = runs_src(rn_col0 + (unsigned)(T + 1));
+#pragma unroll
+                for (int m = 0; m < P / 2; ++m) rw[PAR][m] = src[L * (m + P / 2)];
+            } else if (!LAST) {
+                static_assert(!RUNS || RL % 2 == 0, "a run starts with rw[0] as the lower half");
+                runs_group((unsigned)s / (unsigned)RL + 1u);
+                const f2u* src = runs_src(rn_col0);
+#pragma unroll
+                for (int m = 0; m < P / 2; ++m) rw[PAR ^ 1][m] = src[L * m];
+#pragma unroll
+                for (int m = 0; m < P / 2; ++m) rw[PAR][m] = src[L * (m + P / 2)];
+            }
+        } else
         if (!LAST) {   // the next round's frames travel while this one is transformed
             if constexpr (C::PAIR) {
                 next_src = frame_src(s + 1, 0);
@@ -1417,7 +1497,8 @@ __global__ __launch_bounds__(C::WPB * 64, (JSG_RTAB_OF(C, MIXOP, OUTK) ? 5 : C::
 #pragma unroll
             for (int f = 0; f < F; ++f) {
                 unsigned tk;
-                if constexpr (CARRY) {
+                if constexpr (RUNS) tk = cu_col0;        // (the column itself, clamped: runs_next)
+                else if constexpr (CARRY) {
                     tk = cu_col0 + slot0 + tsub * F + f;
                     tk = tk < a.n_frames ? tk : a.n_frames - 1;
                 } else tk = task_of(it, f);
@@ -1692,6 +1773,7 @@ __global__ __launch_bounds__(C::WPB * 64, (JSG_RTAB_OF(C, MIXOP, OUTK) ? 5 : C::
                             nyB = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(accNy[f]), 32));
                         }
                         const int lwu = lw == 0 ? 64 : lw;                  // lane 0 stores 64 bins further down (one select, not one per register)
+                        if (!RUNS || cu_live)                               // (runs: a column past the end of its row is not stored; uniform)
 #pragma unroll
                         for (int rho = 0; rho < P / 2; ++rho) {
                             const bool fb = L == 32 && (rho & 1);           // the upper frame of a two-frame wavefront
@@ -1732,8 +1814,23 @@ __global__ __launch_bounds__(C::WPB * 64, (JSG_RTAB_OF(C, MIXOP, OUTK) ? 5 : C::
         }
     };
 
-    for (int s = 0; s + 1 < n_fft; ++s) process(s, std::false_type{});
-    process(n_fft - 1, std::true_type{});
+    using t0 = std::integral_constant<int, 0>;
+    if constexpr (RUNS) {   // a.iters runs of RL rounds each, every run written out (a round's place in its run is a compile-time fact);
+                            // the last round of the last run prefetches nothing
+        auto run = [&](int s0, auto last_tag) __attribute__((always_inline)) {
+            for_each_t([&](auto t_tag) __attribute__((always_inline)) {
+                constexpr int T = decltype(t_tag)::value;
+                if constexpr (T + 1 < RL) process(s0 + T, std::false_type{}, t_tag);
+                else process(s0 + T, last_tag, t_tag);
+            }, std::make_integer_sequence<int, RL>{});
+        };
+        int s = 0;
+        for (int r = 0; r + 1 < a.iters; ++r, s += RL) run(s, std::false_type{});
+        run(s, std::true_type{});
+    } else {
+        for (int s = 0; s + 1 < n_fft; ++s) process(s, std::false_type{}, t0{});
+        process(n_fft - 1, std::true_type{}, t0{});
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1932,6 +2029,8 @@ hipError_t launch_stft_strided(const StftKArgs& ka, int mixop, dim3 grid, hipStr
         if constexpr (C::PAIR) return mixop == 0 ? launch_stft_mix<C, 0, 0, STREAM>(ka, grid, s) : hipErrorInvalidValue;
         else
         if (mixop == 3) return launch_stft_mix<C, 3, 0, STREAM>(ka, grid, s);
+        if constexpr (STREAM == 2) return hipErrorInvalidValue;   // (runs: the one-channel kernels only)
+        else
         if (mixop == 0) return launch_stft_mix<C, 0, 0, STREAM>(ka, grid, s);
         return hipErrorInvalidValue;
     }
@@ -1958,5 +2057,7 @@ JSG_FOR_EACH_PLAN(JSG_DECLARE_PLAN)
 // created, not inside the audio thread's first jsg_process_block).
 hipError_t touch_module_a();
 hipError_t touch_module_b();
+// STREAM == 2 ("runs": consecutive columns per wavefront, the overlapped half of a frame kept in registers) exists for the 1024-point plan
+hipError_t launch_runs_Cfg1024(const StftKArgs& ka, int mixop, dim3 grid, hipStream_t s);
 
 }  // namespace jsg

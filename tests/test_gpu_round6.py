@@ -158,3 +158,40 @@ def test_two_stage_plan_in_a_hip_graph_and_with_a_pitched_input(jsg, oracle, tor
         g.replay()
     torch.cuda.synchronize()
     assert torch.equal(cap, eager)
+
+
+# ---- round 6: "runs" (stft_db_kernel STREAM == 2) -- strided one-channel 1024-point launches at exactly 50 % overlap: a wavefront transforms
+# kRunLen consecutive columns and keeps the overlapped half of the raw frame in registers (only the new hop is loaded inside a run).  Same
+# arithmetic: the columns must be those of single launches (which take the plain kernel) bit for bit -- rows shorter than a run, rows that end
+# inside a run (the surplus columns are transformed on clamped loads and NOT stored), ring wrap, per-channel planes, Left / Right, a first
+# frame, unaligned inputs, the tail plane, grids that do not divide the step count, the exact logarithm, linear output. ----
+@pytest.mark.parametrize("C,F,K,mix,W,pos,first,lead,bpc,linear", [
+    (1, 1, 3, "absmean", 4, 3, 0, 0, 0, False), (1, 2, 5, "absmean", 2, 0, 0, 0, 0, False), (1, 3, 4, "absmean", 9, 8, 2, 0, 0, False),
+    (1, 7, 6, "absmean", 7, 0, 0, 1, 0, False), (1, 8, 2, "absmean", 8, 5, 0, 0, 1, False), (1, 9, 7, "absmean", 40, 36, 5, 0, 0, True),
+    (1, 15, 9, "absmean", 15, 14, 0, 3, 3, False), (1, 17, 3, "absmean", 20, 0, 1, 0, 7, False), (1, 701, 6, "absmean", 800, 500, 0, 0, 0, False),
+    (1, 4096, 4, "absmean", 4096, 0, 0, 0, 0, False), (2, 333, 5, "right", 400, 390, 0, 0, 0, False), (3, 129, 4, "left", 129, 0, 4, 0, 1, False),
+    (8, 333, 4, "per_channel", 400, 390, 0, 0, 0, False), (5, 11, 6, "per_channel", 11, 10, 3, 2, 3, True), (8, 4096, 2, "per_channel", 4096, 100, 0, 0, 0, False),
+])
+def test_runs_kernel_equals_single_launches(jsg, oracle, torch_cuda, C, F, K, mix, W, pos, first, lead, bpc, linear):
+    import test_gpu_strided as ts
+    cap = jsg.capi
+    m = {"absmean": cap.MIX_ABSMEAN, "left": cap.MIX_LEFT, "right": cap.MIX_RIGHT, "per_channel": cap.MIX_PER_CHANNEL}[mix]
+    name = ts._run_case(jsg, oracle, torch_cuda, 1024, C, F, K, 512, fb=2, mix=m, W=W, ring_pos=pos, first_frame=first, lead=lead, linear=linear,
+                        blocks_per_cu=bpc, plan_select=1)
+    assert name == "Cfg1024"
+
+
+def test_runs_kernel_with_the_tail_plane_and_the_exact_logarithm(jsg, oracle, torch_cuda):
+    torch = torch_cuda
+    n, hop, F, K, W, pos = 1024, 512, 203, 5, 256, 250
+    plan = jsg.Plan(n, oracle.window(oracle.WIN_HAMMING, n))
+    d_in = _rand(torch, (K, 1, (F - 1) * hop + n), seed=12)
+    for exact in (False, True):
+        got, ref = torch.full((K, W, 512), -7.0, device="cuda"), torch.full((K, W, 512), -7.0, device="cuda")
+        t_got, t_ref = torch.full((K, 1, W), -7.0, device="cuda"), torch.full((K, 1, W), -7.0, device="cuda")
+        kw = dict(feedblocks=2, ring_pos=pos, exact_log=exact)
+        jsg.stft_db_strided(plan, d_in, hop, F, got, d_tail=t_got, **kw)
+        for b in range(K):
+            jsg.stft_db(plan, d_in[b], hop, F, ref[b], d_tail=t_ref[b], **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref) and torch.equal(t_got, t_ref)
