@@ -648,7 +648,9 @@ def main():
             kernel_label = "stft_db_kernel<Cfg4096B, AbsMean, ARGB out> (the workgroups colour their own columns)"
         else:
             kname = jsg.stft_db_strided_kernel_name(plan, d_in[:bpd], hop, F, d_out[:bpd], d_tail=(d_tail[:bpd] if use_tail else None), **mixk)
-            kernel_label = f"stft_db_kernel<{kname}, {'one channel per column' if C == 1 or per_ch else 'AbsMean'}, dB out{', strided' if bpd > 1 else ''}{', tail plane' if use_tail else ''}>"
+            runs = bpd > 1 and kname == "Cfg1024" and 2 * hop == n and (C == 1 or per_ch)      # the launcher's rule (jsg_kernels.hip: `runs`)
+            kernel_label = (f"stft_db_kernel<{kname}, {'one channel per column' if C == 1 or per_ch else 'AbsMean'}, dB out{', strided' if bpd > 1 else ''}"
+                            f"{', runs of 2 consecutive columns per wavefront' if runs else ''}{', tail plane' if use_tail else ''}>")
 
         def dispatch(stream_handle, b=0):
             if c["colour"] and strided:
