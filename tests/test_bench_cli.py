@@ -119,6 +119,22 @@ def test_one_rank_process_group_on_rccl_runs_the_n_gt_1_calls():
 
 
 @pytest.mark.gpu
+def test_plain_gpus_2_self_started_runs_the_kernels_on_the_one_gpu():
+    """`python bench.py --gpus 2` with no launcher around it, real kernels: the parent starts two ranks that share the test box's one GPU (gloo for
+    the barriers; on the driver's node the default is one rank per GPU over RCCL) and time configs[3]."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["JSG_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--dispatches-per-step", "2", "--nbuf", "3", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["workload"].startswith("configs[3]") and j["value"] > 1e7
+    assert "runs of 2 consecutive columns" in j["roofline"]["kernel"]
+
+
+@pytest.mark.gpu
 def test_c4_shard_line_on_one_gpu():
     j = _run([sys.executable, "bench.py", "--config", "c4", "--steps", "2", "--warmup", "1", "--dispatches-per-step", "2", "--no-cpu-baseline", "--no-calibration",
               "--no-boundary"])
