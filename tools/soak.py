@@ -39,4 +39,34 @@ for n, frames, ch, sel in ((512, 3001, 1, 0), (1024, 4096, 1, 0), (1024, 1000, 3
     print(json.dumps(dict(n=n, frames=frames, channels=ch, kernel=sel, launches=6 * B * reps, mismatching_buffers=bad,
                           seconds=round(time.perf_counter() - t0, 2))), flush=True)
     assert bad == 0
+# round 6: the strided dispatches -- the "runs" kernel (1024 points, one channel per column, 50 % overlap: C2 and the per-channel C4 shard) and the
+# two-stage plan Cfg1024B (8 channels AbsMean) -- repeated on two streams at once; every repetition bit-identical to the first
+for label, ch, mix, K, hop_div in (("c2 runs", 1, capi.MIX_ABSMEAN, 24, 2), ("c4 shard runs", 8, capi.MIX_PER_CHANNEL, 3, 2), ("Cfg1024B 8 ch AbsMean", 8, capi.MIX_ABSMEAN, 6, 2)):
+    n, frames = 1024, 4096
+    hop = n // hop_div
+    H = n // 2 + 1; pitch = (H + 31) // 32 * 32
+    plan = jsg.Plan(n, jsg.window(1, n))
+    x = torch.rand((K, ch, (frames - 1) * hop + n), device="cuda") * 2 - 1
+    shape = (K, ch, frames, pitch) if mix == capi.MIX_PER_CHANNEL else (K, frames, pitch)
+    ref = torch.empty(shape, device="cuda")
+    kw = dict(feedblocks=n // hop, mix_mode=mix)
+    name = jsg.stft_db_strided_kernel_name(plan, x, hop, frames, ref, **kw)
+    jsg.stft_db_strided(plan, x, hop, frames, ref, **kw)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    outs = [torch.empty(shape, device="cuda") for _ in range(2)]
+    t0 = time.perf_counter()
+    bad, launches = 0, 0
+    for r in range(150):
+        for si, st in enumerate(streams):
+            for _ in range(4):
+                jsg.stft_db_strided(plan, x, hop, frames, outs[si], stream=st.cuda_stream, blocks_per_cu=(r % 3) * 8, **kw)
+                launches += 1
+        torch.cuda.synchronize()
+        for o in outs:
+            if not torch.equal(o[..., :H], ref[..., :H]):
+                bad += 1
+            o.zero_()
+    print(json.dumps(dict(strided=label, kernel=name, batches=K, channels=ch, dispatches=launches, mismatching_buffers=bad, seconds=round(time.perf_counter() - t0, 2))), flush=True)
+    assert bad == 0
 print("soak ok")
